@@ -1,0 +1,161 @@
+/*
+ * rtt_hip.h — C ABI of librtt_hip.so, the MI355X (gfx950) implementation of the RayTraceTorch
+ * batched ray-propagation hot path.
+ *
+ * The upstream project is pure Python on PyTorch and has no FFI of its own; every entry point
+ * below replaces a *Python* call chain of the reference, cited as file:line relative to the
+ * reference tree.  All pointers except `prog` records passed by the host packer are DEVICE
+ * pointers owned by the caller.  No entry point allocates, frees or synchronises; work is
+ * enqueued on `stream` (a hipStream_t passed as void*).  Return value: 0 on success, a negative
+ * RTT_E_* code otherwise (see rtt_strerror).
+ *
+ * Ray storage is structure-of-arrays: a "plane triple" pointer `p` with leading dimension `ld`
+ * addresses component k of ray i at p[k*ld + i]  (k = 0,1,2 for x,y,z).
+ */
+#ifndef RTT_HIP_H
+#define RTT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTT_ABI_VERSION 1
+#define RTT_MAX_SURFACES 64 /* upper bound on n_surf accepted by every entry point */
+
+/* error codes */
+#define RTT_OK 0
+#define RTT_E_NULL (-1)      /* a required pointer is NULL */
+#define RTT_E_SIZE (-2)      /* n < 0, n_surf out of range, ld < n, index out of range */
+#define RTT_E_KIND (-3)      /* a surface record carries an unknown kind */
+#define RTT_E_LAUNCH (-4)    /* hipLaunchKernel reported an error */
+#define RTT_E_ALIGN (-5)     /* a pointer is not 4-byte aligned */
+
+/* surface geometry kinds (geom/primitives.py:119-497) */
+enum {
+  RTT_SURF_PLANE = 0,      /* z = 0                                   primitives.py:119-143 */
+  RTT_SURF_QUADRIC = 1,    /* c(x^2+y^2)+c(1+k)z^2-2z = 0             primitives.py:244-343 */
+  RTT_SURF_QUADRIC_ZY = 2, /* c y^2 + c(1+k) z^2 - 2z = 0             primitives.py:346-395 */
+  RTT_SURF_CYLINDER = 3,   /* x^2+y^2 = R^2                           primitives.py:190-241 */
+  RTT_SURF_SPHERE = 4,     /* |p|^2 = R^2                             primitives.py:146-187 */
+  RTT_SURF_CONE = 5        /* z^2 - s^2 (x^2+y^2) = 0                 primitives.py:398-497 */
+};
+
+/* surface-level bounds, evaluated in the surface frame at both roots (geom/bounded.py:20-36) */
+enum {
+  RTT_BND_NONE = 0,        /* plain Surface: only the t <= 1e-6 filter primitives.py:28-36 */
+  RTT_BND_DISK = 1,        /* x^2+y^2 <= bnd[0]                       bounded.py:60-64   */
+  RTT_BND_RECT = 2,        /* |x|<=bnd[0] & |y|<=bnd[1]               bounded.py:77-82   */
+  RTT_BND_ELLIPSE = 3,     /* bnd = cos, sin, r_major, r_minor        bounded.py:98-106  */
+  RTT_BND_HALF = 4,        /* |z*c| < 1+1e-6                          bounded.py:123-127,171-174 */
+  RTT_BND_HALF_DISK = 5,   /* HALF & x^2+y^2 <= bnd[0]                bounded.py:151-159 */
+  RTT_BND_SINGLE_CONE = 6, /* z*slope >= -1e-6                        bounded.py:208-217 */
+  RTT_BND_ALWAYS = 7       /* bounded surface whose inBounds is constant true */
+};
+
+/* shape-level bounds, evaluated in the element frame (geom/shape.py:46-55) */
+enum {
+  RTT_SHP_NONE = 0,         /* element.shape is a bare Surface                              */
+  RTT_SHP_SPHERIC_FACE = 1, /* x^2+y^2 <= shp[0]                       spherics.py:40-46    */
+  RTT_SHP_SPHERIC_EDGE = 2, /* shp[0] <= z <= shp[1]                   spherics.py:34-39    */
+  RTT_SHP_CYL_FACE = 3,     /* box aperture shp[0..3]                  cylindrics.py:31-42  */
+  RTT_SHP_CYL_EDGE = 4      /* box & sag(y) limits, shp[4..7]=c0,tz0,c1,tz1 cylindrics.py:44-55 */
+};
+
+/* surface physics (phys/std.py, phys/filter.py) */
+enum {
+  RTT_PHYS_TRANSMIT = 0, /* std.py:221-235 */
+  RTT_PHYS_BLOCK = 1,    /* std.py:237-254 */
+  RTT_PHYS_REFLECT = 2,  /* std.py:91-108  */
+  RTT_PHYS_SNELL = 3,    /* std.py:111-145; phys[0]=ior_in, phys[1]=ior_out,
+                            phys[2]=ior_out/ior_in, phys[3]=ior_in/ior_out */
+  RTT_PHYS_APERTURE = 4  /* filter.py:10-33: dir*=m, imult=m, m = surface bound without invert */
+};
+
+/* flags */
+#define RTT_F_HAS_SHAPE 1    /* two-level transform with re-normalisation (geom/shape.py:37-38) */
+#define RTT_F_SHAPE_ROT_ID 2 /* Rs is exactly the identity */
+#define RTT_F_SURF_ROT_ID 4  /* Rj is exactly the identity */
+#define RTT_F_INVERT 8       /* SurfaceBounded.invert (geom/bounded.py:29-30) */
+#define RTT_F_SENSOR 16      /* Sensor element: record hit_local, intensity (elements/sensor.py:35-37) */
+
+/* One record per (element, surface), 256 bytes, packed on the host from the live parameters. */
+typedef struct RttSurface {
+  int32_t surf_kind, bound_kind, shape_kind, phys_kind;
+  int32_t flags, element_id, surface_id, sensor_slot;
+  float Rs[9], ts[3]; /* element (Shape) transform: local = (p - ts) @ Rs   geom/transform.py:90-93 */
+  float Rj[9], tj[3]; /* surface transform inside the element frame                              */
+  float geom[4];      /* quadrics: c, k, c*(1+k), 0 | cylinder/sphere: R, R*R | cone: s, s*s     */
+  float bnd[4];
+  float shp[8];
+  float phys[4];
+  float pad[12];
+} RttSurface;
+
+/* ---- fused sequential trace: SequentialScene.simulate (scene/sequential.py:12-36) --------------
+ * For s = 0..n_surf-1 in order: test surface s (Element.intersectTest column, elements/parent.py:30-42,
+ * geom/shape.py:25-59), and for rays with t < inf apply Element.forward (elements/parent.py:44-58)
+ * and Rays.scatter_update (rays/ray.py:29-40).  In-place operation (out == in) is allowed.
+ * Sensor surfaces (RTT_F_SENSOR) additionally write, for slot k = sensor_slot, hit_local to
+ * sens_hit[(3*k+c)*sens_ld + i], the pre-update intensity to sens_w[k*sens_ld + i] and 1/0 to
+ * sens_mask[k*sens_ld + i]; all three may be NULL when no surface carries RTT_F_SENSOR. */
+int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                      float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                      const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                      float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
+                      void* stream);
+
+/* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
+ * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
+ * tmin[i] = that t.  Either output may be NULL. */
+int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
+                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                     int32_t* winner, float* tmin, void* stream);
+
+/* ---- one non-sequential bounce: Scene.step (scene/base.py:180-235) ----------------------------
+ * ray_cast + winner dispatch + scatter_update for rays with a hit and intensity > 0.
+ * winner (nullable) receives the ray_cast result.  Sensor outputs as in rtt_trace_seq_f32. */
+int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                         float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                         const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                         int32_t* winner, float* sens_hit, float* sens_w, uint8_t* sens_mask,
+                         int64_t sens_ld, void* stream);
+
+/* ---- Element.intersectTest (elements/parent.py:30-42; geom/shape.py:25-59; primitives.py:38-57)
+ * t_out[s*ld_t + i] = distance to surface s of the program, inf on a miss. */
+int rtt_intersect_test_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
+                           const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                           float* t_out, int64_t ld_t, void* stream);
+
+/* ---- Element.forward / Shape.forward / Surface.forward for ONE surface, every ray, no mask
+ * (elements/parent.py:44-58; geom/shape.py:61-87; geom/primitives.py:59-96).
+ * Outputs (each nullable): t[n], hit_global/normal_global/hit_local/new_dir plane triples with
+ * leading dimension ld_o, imult[n]. */
+int rtt_surface_forward_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
+                            const RttSurface* prog_dev, const RttSurface* prog_host, int surf_index,
+                            float* t, float* hit_global, float* normal_global, float* hit_local,
+                            float* new_dir, float* imult, int64_t ld_o, void* stream);
+
+/* ---- SurfaceFunction.forward(hit_local, ray_dir, normal) on its own (phys/std.py:16-32,91-145,221-254;
+ * phys/filter.py:24-33).  Inputs and new_dir are plane triples with leading dimension ld; only the
+ * physics (and, for RTT_PHYS_APERTURE, bound) fields of the single record are used. */
+int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float* normal, int64_t ld,
+                          int64_t n, const RttSurface* prog_dev, const RttSurface* prog_host,
+                          float* new_dir, float* imult, void* stream);
+
+/* ---- spot-size moments: SpotSizeLoss.forward (optim/goals.py:165-183) -------------------------
+ * pass 0: out[0..2] += sum w, sum w x, sum w y over entries with mask != 0 and w > 0.
+ * pass 1: out[3] += sum sqrt(((x-cx)^2 + (y-cy)^2) * (w / wsum)) over the same entries.
+ * `out` is 4 doubles in device memory that the caller zeroes before pass 0. */
+int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n,
+                         int pass, double cx, double cy, double wsum, double* out, void* stream);
+
+const char* rtt_strerror(int code);
+int rtt_abi_version(void);
+int rtt_surface_record_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTT_HIP_H */

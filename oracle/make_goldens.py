@@ -1,0 +1,199 @@
+"""Generate ``tests/golden/*.npz`` by running the UNMODIFIED upstream reference on CPU.
+
+Container-only tooling (the reference tree does not exist on the GPU box).  Run from the repo root:
+
+    python oracle/make_goldens.py
+
+Only inputs and outputs (arrays) are written; no reference source or bytecode is copied.  The
+scene constructors live in ``tests/scenes.py`` and are shared with the tests, which replay the same
+constructor calls against ``raytracetorch_amd``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_loader  # noqa: E402
+import scenes  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+INF = float("inf")
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def rays_arrays(rays, prefix):
+    return {prefix + "pos": npy(rays.pos), prefix + "dir": npy(rays.dir),
+            prefix + "intensity": npy(rays.intensity), prefix + "id": npy(rays.id)}
+
+
+def clone_rays(ns, rays):
+    return ns.Rays(pos=rays.pos.clone(), dir=rays.dir.clone(), intensity=rays.intensity.clone(),
+                   id=rays.id.clone(), wavelength=rays.wavelength.clone(), batch_size=rays.batch_size)
+
+
+def gen_sequential(ns):
+    for name, (mk_elements, mk_rays, n) in scenes.sequential_cases(ns).items():
+        torch.manual_seed(0)
+        elements = mk_elements()
+        rays0 = mk_rays(n)
+        out = rays_arrays(rays0, "in_")
+        with torch.no_grad():
+            for k, el in enumerate(elements):
+                out[f"it_{k}"] = npy(el.intersectTest(rays0))
+            # Element.forward of the first element on the rays that hit each of its surfaces
+            el = elements[0]
+            tm = el.intersectTest(rays0)
+            for j in range(tm.shape[1]):
+                m = tm[:, j] < INF
+                out[f"fw_{j}_mask"] = npy(m)
+                if bool(m.any()):
+                    p, d, im = el(rays0[m], j)
+                    out[f"fw_{j}_pos"], out[f"fw_{j}_dir"], out[f"fw_{j}_imult"] = npy(p), npy(d), npy(im)
+                    if hasattr(el, "reset"):
+                        el.reset()
+            # states after each element prefix
+            for k in range(len(elements)):
+                for e in elements:
+                    if hasattr(e, "reset"):
+                        e.reset()
+                r = ns.SequentialScene(elements[:k + 1]).simulate(clone_rays(ns, rays0))
+                out.update(rays_arrays(r, f"after_{k}_"))
+            for e in elements:
+                if hasattr(e, "reset"):
+                    e.reset()
+            r = ns.SequentialScene(elements).simulate(clone_rays(ns, rays0))
+            out.update(rays_arrays(r, "out_"))
+            for k, e in enumerate(elements):
+                if hasattr(e, "getHitsTensors") and e.hitLocs:
+                    locs, inten, ids = e.getHitsTensors()
+                    out[f"sensor_{k}_locs"], out[f"sensor_{k}_w"], out[f"sensor_{k}_id"] = npy(locs), npy(inten), npy(ids)
+        np.savez_compressed(os.path.join(OUT, f"seq_{name}.npz"), **out)
+        print(f"seq_{name}: N={n} surfaces={sum(len(e.shape) for e in elements)} "
+              f"alive={(out['out_intensity'] > 0).sum()}")
+
+
+def gen_primitives(ns):
+    cases = dict(scenes.primitive_cases(ns))
+    cases.update(scenes.kat_rays(ns))
+    for name, (mk_surf, mk_rays) in cases.items():
+        torch.manual_seed(1)
+        surf = mk_surf()
+        rays = mk_rays()
+        with torch.no_grad():
+            t_test = surf.intersectTest(rays)
+            t, hit, nrm, hl = surf(rays)
+        out = rays_arrays(rays, "in_")
+        out.update(t_test=npy(t_test), t=npy(t), hit_global=npy(hit), normal_global=npy(nrm), hit_local=npy(hl))
+        np.savez_compressed(os.path.join(OUT, f"prim_{name}.npz"), **out)
+        print(f"prim_{name}: hits={(out['t'] < INF).sum()}/{len(out['t'])}")
+
+
+def naive_rays(ns, scene):
+    import math
+    scene.add_bundle(scenes.disk_bundle(ns, radius=6.5, z=-10.0, rot=[0.03, 0.0, 0.0]), 2048)
+    scene.add_bundle(ns.PointSource(NA=0.9, ray_id=1, transform=ns.RayTransformBundle(
+        translation=[0.0, 0.5, 44.5])), 2048)
+    scene.add_bundle(ns.PointSource(NA=0.8, ray_id=2, transform=ns.RayTransformBundle(
+        translation=[1.0, 0.0, 75.0], rotation=[math.pi, 0.0, 0.0])), 2048)
+    scene.add_bundle(ns.PointSource(NA=0.99, ray_id=3, transform=ns.RayTransformBundle(
+        translation=[0.0, -1.0, 62.0], rotation=[0.0, math.pi / 2, 0.0])), 2048)
+    scene._build_rays()
+
+
+def gen_naive(ns):
+    torch.manual_seed(0)
+    scene = ns.Scene()
+    for el in scenes.naive32(ns):
+        scene.add_element(el)
+    scene._build_index_maps()
+    naive_rays(ns, scene)
+    rays0 = clone_rays(ns, scene.rays)
+    out = rays_arrays(rays0, "in_")
+    with torch.no_grad():
+        out["t_matrix"] = npy(torch.cat([el.intersectTest(rays0) for el in scene.elements], dim=1))
+        hit, el_ids, sf_ids = scene.ray_cast(rays0)
+        out.update(hit_mask=npy(hit), el_ids=npy(el_ids), sf_ids=npy(sf_ids))
+        scene.step()
+        out.update(rays_arrays(scene.rays, "step1_"))
+        sensor = scene.elements[-1]
+        if sensor.hitLocs:
+            locs, inten, ids = sensor.getHitsTensors()
+            out.update(sensor_locs=npy(locs), sensor_w=npy(inten))
+    np.savez_compressed(os.path.join(OUT, "naive32.npz"), **out)
+    win = out["t_matrix"].argmin(1)[out["hit_mask"]]
+    print(f"naive32: N={len(out['hit_mask'])} hit={out['hit_mask'].sum()} distinct winners={len(np.unique(win))}")
+
+
+def gen_spot(ns, dtype, tag):
+    torch.manual_seed(0)
+    n = 65536
+    lens, sensor = scenes.spot_system(ns, grads=True)
+    bundle = ns.CollimatedDisk(radius=4.0, ray_id=0, dtype=dtype,
+                               transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0], dtype=dtype))
+    if dtype == torch.float64:
+        lens.double(); sensor.double(); bundle.double()
+    rays = bundle.sample(n)
+    out = {"first_pos": npy(rays.pos[:64]), "first_dir": npy(rays.dir[:64]),
+           "checksum": np.array([rays.pos.double().sum().item(), rays.dir.double().sum().item()])}
+    scene = ns.SequentialScene([lens, sensor])
+    scene.simulate(rays)
+    locs, w, _ = sensor.getHitsTensors()
+    xy = locs[:, :2]
+    act = w > 0
+    xy, w = xy[act], w[act]
+    ws = w.sum().clamp(min=1e-12)
+    cx, cy = (xy[:, 0] * w).sum() / ws, (xy[:, 1] * w).sum() / ws
+    loss = torch.sqrt(((xy[:, 0] - cx) ** 2 + (xy[:, 1] - cy) ** 2) * (w / ws)).sum()
+    loss.backward()
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    out.update(loss=npy(loss), n_hits=np.array(int(act.sum())), centroid=np.array([cx.item(), cy.item()]),
+               g_c1=npy(s0.c.grad), g_c2=npy(s1.c.grad), g_trans0=npy(s0.transform.trans.grad),
+               g_trans1=npy(s1.transform.trans.grad), g_ior_glass=npy(lens.ior_glass.grad))
+    np.savez_compressed(os.path.join(OUT, f"spot_{tag}.npz"), **out)
+    print(f"spot_{tag}: loss={loss.item():.6f} hits={int(act.sum())} g_c1={s0.c.grad.item():.4f} "
+          f"g_c2={s1.c.grad.item():.4f} g_t0={s0.transform.trans.grad.tolist()} "
+          f"g_t1={s1.transform.trans.grad.tolist()} g_ior={lens.ior_glass.grad.item():.4f}")
+
+
+def gen_grad_kats(ns):
+    """tests/test_primitive.py:166-307 of the reference: d(sum hit)/d(translation)."""
+    out = {}
+    tr = torch.tensor([0.0, 0.0, 5.0], requires_grad=True)
+    plane = ns.Plane(transform=ns.RayTransform(translation=tr, trans_grad=True, rot_grad=False))
+    d = torch.tensor([[0.0, 1.0, 1.0]]); d = d / d.norm(dim=1, keepdim=True)
+    rays = ns.Rays.initialize(torch.tensor([[0.0, 0.0, 0.0]]), d)
+    _, hit, _, _ = plane(rays)
+    hit.sum().backward()
+    out["plane_hit"], out["plane_grad"] = npy(hit), npy(plane.transform.trans.grad)
+    tr = torch.tensor([0.0, 0.0, 5.0], requires_grad=True)
+    quad = ns.Quadric(transform=ns.RayTransform(translation=tr, trans_grad=True, rot_grad=False), c=0.01, k=0.0, c_grad=True)
+    rays = ns.Rays.initialize(torch.tensor([[5.0, 0.0, 0.0]]), torch.tensor([[0.0, 0.0, 1.0]]))
+    _, hit, _, _ = quad(rays)
+    hit.sum().backward()
+    out["quadric_hit"], out["quadric_grad"], out["quadric_grad_c"] = npy(hit), npy(quad.transform.trans.grad), npy(quad.c.grad)
+    np.savez_compressed(os.path.join(OUT, "grad_kats.npz"), **out)
+    print("grad_kats:", {k: v.tolist() for k, v in out.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_loader.load()
+    ns = scenes.namespace_from_package(ref)
+    gen_primitives(ns)
+    gen_sequential(ns)
+    gen_naive(ns)
+    gen_spot(ns, torch.float32, "f32")
+    gen_spot(ns, torch.float64, "f64")
+    gen_grad_kats(ns)
+
+
+if __name__ == "__main__":
+    main()

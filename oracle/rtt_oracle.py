@@ -1,0 +1,413 @@
+"""CPU oracle for the ray-propagation hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, on plain CPU torch tensors, the per-ray arithmetic of the reference's
+sequential and nearest-hit trace so that the HIP kernels can be checked against it.  Only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import
+it; the product package never does.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against golden
+vectors in ``tests/golden/*.npz`` that were produced by running the unmodified reference
+(``oracle/make_goldens.py``), and against the known answers of the reference's own
+``tests/test_primitive.py``.
+
+The oracle interprets the same packed *surface program* the kernels consume (one 256-byte record
+per (element, surface), layout declared in ``include/rtt_hip.h``), but shares no code with the
+kernels or with the host packer: the record layout and the enum values are restated below.
+
+All citations are file:line relative to the reference tree.
+"""
+import numpy as np
+import torch
+
+INF = float("inf")
+EPS = 1e-6  # geom/primitives.py:6 (intersectEpsilon) and :21 (Surface.epsilon)
+
+SURFACE_DTYPE = np.dtype([
+    ("surf_kind", "<i4"), ("bound_kind", "<i4"), ("shape_kind", "<i4"), ("phys_kind", "<i4"),
+    ("flags", "<i4"), ("element_id", "<i4"), ("surface_id", "<i4"), ("sensor_slot", "<i4"),
+    ("Rs", "<f4", (9,)), ("ts", "<f4", (3,)), ("Rj", "<f4", (9,)), ("tj", "<f4", (3,)),
+    ("geom", "<f4", (4,)), ("bnd", "<f4", (4,)), ("shp", "<f4", (8,)), ("phys", "<f4", (4,)),
+    ("pad", "<f4", (12,)),
+])
+assert SURFACE_DTYPE.itemsize == 256
+
+PLANE, QUADRIC, QUADRIC_ZY, CYLINDER, SPHERE, CONE = range(6)
+B_NONE, B_DISK, B_RECT, B_ELLIPSE, B_HALF, B_HALF_DISK, B_SINGLE_CONE, B_ALWAYS = range(8)
+S_NONE, S_SPHERIC_FACE, S_SPHERIC_EDGE, S_CYL_FACE, S_CYL_EDGE = range(5)
+P_TRANSMIT, P_BLOCK, P_REFLECT, P_SNELL, P_APERTURE = range(5)
+F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR = 1, 2, 4, 8, 16
+
+
+class _Rec:
+    """One surface record with its float fields as python floats / torch tensors of `dtype`."""
+
+    def __init__(self, rec, dtype):
+        self.surf_kind = int(rec["surf_kind"]); self.bound_kind = int(rec["bound_kind"])
+        self.shape_kind = int(rec["shape_kind"]); self.phys_kind = int(rec["phys_kind"])
+        self.flags = int(rec["flags"]); self.element_id = int(rec["element_id"])
+        self.surface_id = int(rec["surface_id"]); self.sensor_slot = int(rec["sensor_slot"])
+        t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32)).to(dtype)
+        self.Rs = t(rec["Rs"]).reshape(3, 3); self.ts = t(rec["ts"])
+        self.Rj = t(rec["Rj"]).reshape(3, 3); self.tj = t(rec["tj"])
+        self.geom = t(rec["geom"]); self.bnd = t(rec["bnd"]); self.shp = t(rec["shp"])
+        self.phys = t(rec["phys"])
+        self.dtype = dtype
+
+
+def _rowmat(v, R):
+    """v @ R for row vectors, spelled out so the summation order is fixed (geom/transform.py:92-93)."""
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    return torch.stack([x * R[0, j] + y * R[1, j] + z * R[2, j] for j in range(3)], dim=1)
+
+
+def _rowmat_T(v, R):
+    """v @ R.T (geom/transform.py:116-117, geom/primitives.py:94, geom/shape.py:85)."""
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    return torch.stack([x * R[j, 0] + y * R[j, 1] + z * R[j, 2] for j in range(3)], dim=1)
+
+
+def _normalize(d):
+    """Rays.__post_init__ (rays/ray.py:22-25): F.normalize(dir, p=2, dim=1), eps 1e-12."""
+    n = torch.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])
+    return d / torch.clamp_min(n, 1e-12).unsqueeze(1)
+
+
+def _nanmin(a, b):
+    """torch.min over a stacked dim propagates NaN (geom/primitives.py:34, geom/bounded.py:34)."""
+    return torch.min(torch.stack([a, b]), dim=0)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# roots of the ray/surface equation in the surface frame
+# --------------------------------------------------------------------------------------------
+def solve_roots(S, pl, dl):
+    ox, oy, oz = pl[:, 0], pl[:, 1], pl[:, 2]
+    dx, dy, dz = dl[:, 0], dl[:, 1], dl[:, 2]
+    eps = torch.tensor(EPS, dtype=torch.float32).to(S.dtype)
+    inf = torch.full_like(ox, INF)
+    k = S.surf_kind
+    if k == PLANE:  # geom/primitives.py:124-136
+        safe = torch.where(torch.abs(dz) < eps, torch.tensor(1e-8, dtype=S.dtype), dz)
+        return [-oz / safe]
+    if k == SPHERE:  # geom/primitives.py:155-181
+        b = 2.0 * (ox * dx + oy * dy + oz * dz)
+        c = (ox * ox + oy * oy + oz * oz) - S.geom[1]
+        disc = b * b - 4 * c
+        hit = disc >= 0
+        sq = torch.sqrt(torch.where(hit, disc, torch.zeros_like(disc)))
+        t1 = (-b - sq) / 2.0
+        t2 = (-b + sq) / 2.0
+        return [torch.where(hit, t1, inf), torch.where(hit, t2, inf)]
+    if k == CYLINDER:  # geom/primitives.py:201-231
+        A = dx * dx + dy * dy
+        B = 2.0 * (ox * dx + oy * dy)
+        C = (ox * ox + oy * oy) - S.geom[1]
+        disc = B * B - 4.0 * A * C
+        hit = disc >= 0
+        sq = torch.sqrt(torch.abs(disc))
+        t1 = (-B - sq) / (2.0 * A)
+        t2 = (-B + sq) / (2.0 * A)
+        return [torch.where(hit, t1, inf), torch.where(hit, t2, inf)]
+    if k in (QUADRIC, QUADRIC_ZY):  # geom/primitives.py:266-328, :356-377
+        c, c1k = S.geom[0], S.geom[2]
+        two_c, two_c1k = 2 * c, 2 * c1k
+        if k == QUADRIC:
+            A = c * (dx * dx + dy * dy) + c1k * (dz * dz)
+            B = two_c * (ox * dx + oy * dy) + two_c1k * oz * dz - 2 * dz
+            C = c * (ox * ox + oy * oy) + c1k * (oz * oz) - 2 * oz
+        else:
+            A = c * (dy * dy) + c1k * (dz * dz)
+            B = two_c * (oy * dy) + two_c1k * oz * dz - 2 * dz
+            C = c * (oy * oy) + c1k * (oz * oz) - 2 * oz
+        return _solve_quadratic_linear_fallback(A, B, C, eps, inf, abs_disc=True)
+    if k == CONE:  # geom/primitives.py:416-466
+        k2 = S.geom[1]
+        A = dz * dz - k2 * (dx * dx + dy * dy)
+        B = 2.0 * (oz * dz - k2 * (ox * dx + oy * dy))
+        C = oz * oz - k2 * (ox * ox + oy * oy)
+        return _solve_quadratic_linear_fallback(A, B, C, eps, inf, abs_disc=False)
+    raise ValueError(f"unknown surface kind {k}")
+
+
+def _solve_quadratic_linear_fallback(A, B, C, eps, inf, abs_disc):
+    """Quadric._solve_quadratic (geom/primitives.py:290-320) / Cone (:436-466)."""
+    disc = B * B - 4 * A * C
+    hit = disc >= 0
+    lin = torch.abs(A) < eps
+    if abs_disc:
+        sq = torch.sqrt(torch.abs(disc))
+    else:
+        sq = torch.sqrt(torch.where(hit, disc, torch.zeros_like(disc)))
+    A_safe = torch.where(lin, torch.ones_like(A), A)
+    t1 = (-B - sq) / (2.0 * A_safe)
+    t2 = (-B + sq) / (2.0 * A_safe)
+    B_safe = torch.where(torch.abs(B) < eps, eps.expand_as(B), B)
+    t_lin = -C / B_safe
+    t1 = torch.where(hit, t1, inf)
+    t2 = torch.where(hit, t2, inf)
+    return [torch.where(lin, t_lin, t1), torch.where(lin, t_lin, t2)]
+
+
+# --------------------------------------------------------------------------------------------
+# bounds
+# --------------------------------------------------------------------------------------------
+def surface_in_bounds(S, h):
+    """SurfaceBounded.inBounds variants, surface frame, without `invert` (geom/bounded.py)."""
+    x, y, z = h[:, 0], h[:, 1], h[:, 2]
+    b = S.bound_kind
+    one_eps = torch.tensor(1 + EPS, dtype=torch.float32).to(S.dtype)
+    if b == B_DISK:  # bounded.py:60-64
+        return (x * x + y * y) <= S.bnd[0]
+    if b == B_RECT:  # bounded.py:77-82
+        return (torch.abs(x) <= S.bnd[0]) & (torch.abs(y) <= S.bnd[1])
+    if b == B_ELLIPSE:  # bounded.py:98-106
+        cs, sn, rM, rm = S.bnd
+        dM = x * cs - y * sn
+        dm = x * sn + y * cs
+        return ((dM / rM) ** 2 + (dm / rm) ** 2) <= 1.0
+    if b == B_HALF:  # bounded.py:123-127, :171-174
+        return torch.abs(z * S.geom[0]) < one_eps
+    if b == B_HALF_DISK:  # bounded.py:151-159
+        return (torch.abs(z * S.geom[0]) < one_eps) & ((x * x + y * y) <= S.bnd[0])
+    if b == B_SINGLE_CONE:  # bounded.py:208-217
+        return (z * S.geom[0]) >= torch.tensor(-EPS, dtype=torch.float32).to(S.dtype)
+    if b == B_ALWAYS:
+        return torch.ones_like(x, dtype=torch.bool)
+    raise ValueError(f"surface_in_bounds on bound kind {b}")
+
+
+def _sag(c, tz, y):
+    """HalfCyl.sagittalZ with a per-ray height (geom/bounded.py:176-186)."""
+    r_sq = y * y
+    term = torch.relu(1.0 - (c * c) * r_sq)
+    return (c * r_sq) / (1.0 + torch.sqrt(term)) + tz
+
+
+def shape_in_bounds(S, he):
+    """Shape.inBounds(hit, j) in the element frame (geom/spherics.py:27-46, geom/cylindrics.py:23-55)."""
+    x, y, z = he[:, 0], he[:, 1], he[:, 2]
+    k = S.shape_kind
+    if k == S_SPHERIC_FACE:
+        return (x * x + y * y) <= S.shp[0]
+    if k == S_SPHERIC_EDGE:
+        return (z >= S.shp[0]) & (z <= S.shp[1])
+    if k in (S_CYL_FACE, S_CYL_EDGE):
+        # shp[0..3] = x_max+1e-5, x_min-1e-5, y_max+1e-5, y_min-1e-5
+        ap = (x <= S.shp[0]) & (x >= S.shp[1]) & (y <= S.shp[2]) & (y >= S.shp[3])
+        if k == S_CYL_FACE:
+            return ap
+        zf = _sag(S.shp[4], S.shp[5], y)
+        zb = _sag(S.shp[6], S.shp[7], y)
+        in_z = (z >= zf + 1e-4) & (z <= zb - 1e-4)
+        return in_z & ap
+    raise ValueError(f"shape_in_bounds on shape kind {k}")
+
+
+# --------------------------------------------------------------------------------------------
+# one surface: frames, t, test column, forward, physics
+# --------------------------------------------------------------------------------------------
+def to_frames(S, p, d):
+    """Global -> element frame (+ re-normalisation) -> surface frame.
+    geom/shape.py:37-38, rays/ray.py:84-97,:25, geom/transform.py:90-93, geom/primitives.py:50."""
+    if S.flags & F_HAS_SHAPE:
+        pe = _rowmat(p - S.ts[None, :], S.Rs)
+        de = _rowmat(d, S.Rs)
+        den = _normalize(de)
+    else:
+        pe, de, den = p, d, d
+    pl = _rowmat(pe - S.tj[None, :], S.Rj)
+    dl = _rowmat(den, S.Rj)
+    return pe, de, pl, dl
+
+
+def solve_t(S, pl, dl):
+    """Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36)."""
+    roots = solve_roots(S, pl, dl)
+    eps = torch.tensor(EPS, dtype=torch.float32).to(S.dtype)
+    out = []
+    for r in roots:
+        bad = r <= eps
+        if S.bound_kind != B_NONE:
+            h = pl + r[:, None] * dl
+            keep = surface_in_bounds(S, h)
+            if S.flags & F_INVERT:
+                keep = ~keep
+            bad = bad | ~keep
+        out.append(torch.where(bad, torch.full_like(r, INF), r))
+    t = out[0]
+    for r in out[1:]:
+        t = _nanmin(t, r)
+    return t
+
+
+def test_column(S, p, d):
+    """Column of Element.intersectTest for this surface (geom/shape.py:42-56 or primitives.py:38-57)."""
+    pe, de, pl, dl = to_frames(S, p, d)
+    t = solve_t(S, pl, dl)
+    if S.flags & F_HAS_SHAPE:
+        he = pe + t[:, None] * de  # un-normalised element-frame direction, shape.py:47
+        valid = (t < INF) & shape_in_bounds(S, he)
+        t = torch.where(valid, t, torch.full_like(t, INF))
+    return t
+
+
+def surface_normal(S, hl):
+    """_getNormal in the surface frame."""
+    x, y, z = hl[:, 0], hl[:, 1], hl[:, 2]
+    k = S.surf_kind
+    zero = torch.zeros_like(x)
+    if k == PLANE:  # primitives.py:138-143
+        return torch.stack([zero, zero, torch.ones_like(x)], dim=1)
+    if k == SPHERE:  # primitives.py:183-187
+        return hl / S.geom[0]
+    if k == CYLINDER:  # primitives.py:233-241
+        return torch.stack([x / S.geom[0], y / S.geom[0], zero], dim=1)
+    if k in (QUADRIC, QUADRIC_ZY):  # primitives.py:330-343, :379-395
+        two_c, two_c1k = 2 * S.geom[0], 2 * S.geom[2]
+        nx = two_c * x if k == QUADRIC else zero
+        ny = two_c * y
+        nz = two_c1k * z - 2.0
+        raw = torch.stack([nx, ny, nz], dim=1)
+        ln = torch.sqrt(nx * nx + ny * ny + nz * nz)
+        return -(raw / (ln[:, None] + 1e-8))
+    if k == CONE:  # primitives.py:468-497
+        k2 = S.geom[1]
+        raw = torch.stack([-k2 * x, -k2 * y, z], dim=1)
+        ln = torch.sqrt(raw[:, 0] ** 2 + raw[:, 1] ** 2 + raw[:, 2] ** 2)
+        unit = raw / (ln[:, None] + 1e-8)
+        up = torch.tensor([0.0, 0.0, 1.0], dtype=S.dtype).expand_as(raw)
+        return torch.where((ln > 1e-8)[:, None], unit, up)
+    raise ValueError(k)
+
+
+def surface_forward(S, p, d):
+    """Shape.forward / Surface.forward for every ray (geom/shape.py:61-87, primitives.py:59-96).
+    Returns t, hit_global, normal_global, hit_local."""
+    pe, de, pl, dl = to_frames(S, p, d)
+    t = solve_t(S, pl, dl)
+    hit_g = p + t[:, None] * d  # shape.py:81 / primitives.py:85
+    hl = pl + t[:, None] * dl   # primitives.py:86
+    n = _rowmat_T(surface_normal(S, hl), S.Rj)  # primitives.py:94
+    if S.flags & F_HAS_SHAPE:
+        n = _rowmat_T(n, S.Rs)  # shape.py:85
+    return t, hit_g, n, hl
+
+
+def apply_physics(S, hl, d, n):
+    """SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult)."""
+    k = S.phys_kind
+    ones = torch.ones_like(d[:, 0])
+    if k == P_TRANSMIT:  # std.py:227-235
+        return d, ones
+    if k == P_BLOCK:  # std.py:243-254
+        return torch.zeros_like(d), torch.zeros_like(ones)
+    if k == P_REFLECT:  # std.py:97-108
+        cos = (d[:, 0] * n[:, 0] + d[:, 1] * n[:, 1] + d[:, 2] * n[:, 2])[:, None]
+        return d - 2 * cos * n, ones
+    if k == P_SNELL:  # std.py:123-145
+        dot = (d[:, 0] * n[:, 0] + d[:, 1] * n[:, 1] + d[:, 2] * n[:, 2])[:, None]
+        ent = dot < 0
+        ne = torch.where(ent, n, -n)
+        c1 = torch.abs(dot)
+        mu = torch.where(ent, S.phys[2], S.phys[3])
+        term = 1.0 - mu * mu * (1.0 - c1 * c1)
+        tir = term < 0
+        c2 = torch.sqrt(torch.relu(term))
+        refr = mu * d + (mu * c1 - c2) * ne
+        refl = d - 2 * dot * n
+        return torch.where(tir, refl, refr), ones
+    if k == P_APERTURE:  # filter.py:24-33
+        m = surface_in_bounds(S, hl).to(d.dtype)
+        return d * m[:, None], m
+    raise ValueError(k)
+
+
+def element_forward(S, p, d):
+    """Element.forward (elements/parent.py:44-58) -> new_pos, new_dir, imult, hit_local."""
+    t, hit_g, n, hl = surface_forward(S, p, d)
+    nd, m = apply_physics(S, hl, d, n)
+    return hit_g, nd, m, hl
+
+
+# --------------------------------------------------------------------------------------------
+# drivers
+# --------------------------------------------------------------------------------------------
+def _records(prog, dtype):
+    prog = np.asarray(prog)
+    assert prog.dtype == SURFACE_DTYPE
+    return [_Rec(prog[i], dtype) for i in range(prog.shape[0])]
+
+
+def _as(x, dtype):
+    return torch.as_tensor(np.asarray(x)).to(dtype).clone()
+
+
+def trace_sequential(prog, pos, dir_, inten, dtype=torch.float32):
+    """SequentialScene.simulate (scene/sequential.py:12-36) on [N,3] pos/dir and [N] intensity.
+
+    Returns dict(pos, dir, intensity, sensor=[(slot, mask, hit_local, intensity_before), ...]).
+    Predicated (`where`) instead of gather/scatter: identical arithmetic per ray."""
+    p, d, I = _as(pos, dtype), _as(dir_, dtype), _as(inten, dtype)
+    sensor = []
+    for S in _records(prog, dtype):
+        t = test_column(S, p, d)
+        mask = t < INF
+        hit_g, nd, m, hl = element_forward(S, p, d)
+        if S.flags & F_SENSOR:  # elements/sensor.py:35-37: intensity before the multiplier
+            sensor.append((S.sensor_slot, mask.clone(), hl.clone(), I.clone()))
+        p = torch.where(mask[:, None], hit_g, p)
+        d = torch.where(mask[:, None], nd, d)
+        I = torch.where(mask, I * m, I)  # rays/ray.py:38-40
+    return dict(pos=p, dir=d, intensity=I, sensor=sensor)
+
+
+def intersect_matrix(prog, pos, dir_, dtype=torch.float32):
+    """cat of Element.intersectTest over all elements: [N, S] (scene/base.py:164-168)."""
+    p, d = _as(pos, dtype), _as(dir_, dtype)
+    return torch.stack([test_column(S, p, d) for S in _records(prog, dtype)], dim=1)
+
+
+def ray_cast(prog, pos, dir_, dtype=torch.float32):
+    """Scene.ray_cast (scene/base.py:144-178): (tmin[N], winner[N] int64 global surface index,
+    -1 where no surface is hit)."""
+    tm = intersect_matrix(prog, pos, dir_, dtype)
+    tmin, idx = torch.min(tm, dim=1)
+    win = torch.where(tmin < INF, idx, torch.full_like(idx, -1))
+    return tmin, win, tm
+
+
+def step_nearest(prog, pos, dir_, inten, dtype=torch.float32):
+    """Scene.step (scene/base.py:180-235)."""
+    p, d, I = _as(pos, dtype), _as(dir_, dtype), _as(inten, dtype)
+    tmin, win, _ = ray_cast(prog, p, d, dtype)
+    active = (win >= 0) & (I > 0)
+    np_, nd_, nI = p.clone(), d.clone(), I.clone()
+    sensor = []
+    for s, S in enumerate(_records(prog, dtype)):
+        m = active & (win == s)
+        if not bool(m.any()):
+            if S.flags & F_SENSOR:
+                sensor.append((S.sensor_slot, m, torch.zeros_like(p), I.clone()))
+            continue
+        hit_g, nd, im, hl = element_forward(S, p, d)
+        if S.flags & F_SENSOR:
+            sensor.append((S.sensor_slot, m.clone(), hl.clone(), I.clone()))
+        np_ = torch.where(m[:, None], hit_g, np_)
+        nd_ = torch.where(m[:, None], nd, nd_)
+        nI = torch.where(m, I * im, nI)
+    return dict(pos=np_, dir=nd_, intensity=nI, winner=win, tmin=tmin, sensor=sensor)
+
+
+def spot_size_loss(x, y, w, target_xy=None):
+    """SpotSizeLoss.forward inner formula (optim/goals.py:165-183) for one bundle."""
+    x, y, w = (torch.as_tensor(a) for a in (x, y, w))
+    act = w > 0
+    if not bool(act.any()):
+        return None
+    x, y, w = x[act], y[act], w[act]
+    ws = w.sum().clamp(min=1e-12)
+    if target_xy is None:
+        cx, cy = (x * w).sum() / ws, (y * w).sum() / ws
+    else:
+        cx, cy = target_xy
+    return torch.sqrt(((x - cx) ** 2 + (y - cy) ** 2) * (w / ws)).sum()

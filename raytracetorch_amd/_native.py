@@ -1,0 +1,120 @@
+"""ctypes binding of ``librtt_hip.so`` (C ABI in ``include/rtt_hip.h``).
+
+There is deliberately no fallback: if the shared library is missing, fails to load, or a tensor
+is not on a HIP device, the call raises.  Nothing in this package computes ray geometry on the CPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import program as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librtt_hip.so")
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+
+_SIGNATURES = {
+    "rtt_trace_seq_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
+                          _vp, _vp, _vp, _i64, _vp],
+    "rtt_ray_cast_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp],
+    "rtt_step_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
+                             _vp, _vp, _vp, _vp, _i64, _vp],
+    "rtt_intersect_test_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _i64, _vp],
+    "rtt_surface_forward_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i64, _vp],
+    "rtt_apply_physics_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
+    "rtt_spot_moments_f32": [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _dbl, _dbl, _vp, _vp],
+}
+EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes")
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C raytracetorch_amd/csrc`. There is no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, args in _SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = _int
+    L.rtt_strerror.argtypes = [_int]
+    L.rtt_strerror.restype = ctypes.c_char_p
+    L.rtt_abi_version.restype = _int
+    L.rtt_surface_record_bytes.restype = _int
+    if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
+        raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")
+    _lib = L
+    return L
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {lib().rtt_strerror(code).decode()} ({code})")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != "cuda":
+            raise RuntimeError(
+                "raytracetorch_amd runs ray geometry only on a HIP device (torch device 'cuda'); "
+                f"got a tensor on '{t.device}'. There is no CPU fallback.")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_handle(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class DeviceProgram:
+    """Host records + their device copy.  Uploads are skipped while the bytes are unchanged."""
+
+    _cache = {}
+
+    def __init__(self, host: np.ndarray, dev: torch.Tensor):
+        self.host = host
+        self.dev = dev
+
+    @classmethod
+    def upload(cls, prog: np.ndarray, device) -> "DeviceProgram":
+        device = torch.device(device)
+        prog = np.ascontiguousarray(prog)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), prog.shape[0])
+        raw = prog.tobytes()
+        hit = cls._cache.get(key)
+        if hit is not None and hit[0] == raw:
+            return hit[1]
+        dev = torch.from_numpy(prog.view(np.uint8).reshape(-1).copy()).to(device)
+        dp = cls(prog, dev)
+        cls._cache[key] = (raw, dp)
+        return dp
+
+    @property
+    def n(self):
+        return int(self.host.shape[0])
+
+    @property
+    def host_ptr(self):
+        return self.host.ctypes.data

@@ -1,0 +1,5 @@
+from .parent import Element, ElementCustom
+from .lens import SingletLens, CylSingletLens, DoubletLens, TripletLens
+from .sensor import Sensor
+from .mirror import Mirror, SphericalMirror, CylindricalMirror, ParabolicMirror, ParabolicMirrorXZ
+from .aperture import CircularAperture, RectangularAperture, EllipticAperture

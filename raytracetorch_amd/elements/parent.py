@@ -1,0 +1,50 @@
+"""``Element`` = a shape plus one physics functor per surface (reference: elements/parent.py:8-81).
+
+``intersectTest(rays) -> [N, K]`` and ``forward(rays, j) -> (new_pos, new_dir, intensity_mult)``
+keep the reference contract; both run in the HIP kernels from the element's surface records.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .. import program as P
+from ..geom import Shape
+from ..phys import SurfaceFunction
+
+
+class Element(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.shape = Shape()
+        self.surface_functions = nn.ModuleList()
+
+    # ---- record description -------------------------------------------------------------------
+    def _record(self, j: int):
+        rec = self.shape._record(j)
+        self.surface_functions[j]._fill_physics(rec)
+        return rec
+
+    def _program(self):
+        return np.stack([self._record(j) for j in range(len(self.shape))])
+
+    # ---- reference API ------------------------------------------------------------------------
+    def intersectTest(self, rays):
+        return K.intersect_test(rays, self._program())
+
+    def _forward_full(self, rays, surf_idx):
+        return K.surface_forward(rays, self._record(surf_idx)[None], 0, want_phys=True)
+
+    def forward(self, rays, surf_idx):
+        o = self._forward_full(rays, surf_idx)
+        return o["hit_global"], o["new_dir"], o["imult"]
+
+
+class ElementCustom(Element):
+    """One functor shared by every surface of a given shape (elements/parent.py:73-81)."""
+
+    def __init__(self, shape: Shape, surface_function: SurfaceFunction, device: torch.device = None):
+        super().__init__()
+        self.shape = shape
+        self.surface_functions.extend(len(shape) * [surface_function])

@@ -1,0 +1,175 @@
+"""Python launchers for the C-ABI entry points of ``librtt_hip.so``.
+
+Each function validates devices / shapes / dtypes on the host, allocates outputs with torch (the
+C side never allocates) and enqueues one kernel on the current torch stream of the rays' device.
+"""
+import numpy as np
+import torch
+
+from . import _native as N
+from . import program as P
+from .rays.ray import Rays
+
+
+def _check_rays(rays: Rays):
+    N.require_device(rays._pos, rays._dir, rays.intensity)
+    n = len(rays)
+    for name, t, shape in (("pos", rays._pos, (3, n)), ("dir", rays._dir, (3, n)),
+                           ("intensity", rays.intensity, (n,))):
+        if t.dtype != torch.float32:
+            raise TypeError(f"rays.{name} must be float32 for the HIP path, got {t.dtype}")
+        if tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"rays.{name} must be a contiguous tensor of shape {shape}")
+    return n
+
+
+def _sensor_buffers(prog, n, device):
+    k = P.n_sensor_slots(prog)
+    if k == 0:
+        return None, None, None
+    hit = torch.empty((k, 3, n), device=device, dtype=torch.float32)
+    w = torch.empty((k, n), device=device, dtype=torch.float32)
+    mask = torch.zeros((k, n), device=device, dtype=torch.uint8)
+    return hit, w, mask
+
+
+def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None):
+    """SequentialScene.simulate on the device.  Writes into `out` (default: in place into `rays`).
+    Returns (sens_hit [K,3,N], sens_w [K,N], sens_mask [K,N] uint8) or (None, None, None)."""
+    n = _check_rays(rays)
+    if out is None:
+        out = rays
+    elif _check_rays(out) != n:
+        raise ValueError("`out` must hold the same number of rays")
+    dev = rays.device
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev)
+    if n == 0 or prog.shape[0] == 0:
+        if out is not rays:
+            out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
+        return sens_hit, sens_w, sens_mask
+    dp = N.DeviceProgram.upload(prog, dev)
+    with torch.cuda.device(dev):
+        code = N.lib().rtt_trace_seq_f32(
+            N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+            N.ptr(out._pos), N.ptr(out._dir), N.ptr(out.intensity), n, n,
+            N.ptr(dp.dev), dp.host_ptr, dp.n,
+            N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, N.stream_handle(dev))
+    N.check(code, "rtt_trace_seq_f32")
+    return sens_hit, sens_w, sens_mask
+
+
+def intersect_test(rays: Rays, prog: np.ndarray) -> torch.Tensor:
+    """[N, S] matrix of distances (inf = miss), returned as a transposed view of [S, N] planes."""
+    n = _check_rays(rays)
+    s = prog.shape[0]
+    t = torch.empty((s, n), device=rays.device, dtype=torch.float32)
+    if n and s:
+        dp = N.DeviceProgram.upload(prog, rays.device)
+        with torch.cuda.device(rays.device):
+            code = N.lib().rtt_intersect_test_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n,
+                N.ptr(t), n, N.stream_handle(rays.device))
+        N.check(code, "rtt_intersect_test_f32")
+    return t.t()
+
+
+def surface_forward(rays: Rays, prog: np.ndarray, index: int, want_phys: bool):
+    """Forward of ONE surface on every ray.  Returns dict with t [N], hit_global / normal_global /
+    hit_local [N,3] views, and when `want_phys` new_dir [N,3], imult [N]."""
+    n = _check_rays(rays)
+    dev = rays.device
+    mk3 = lambda: torch.empty((3, n), device=dev, dtype=torch.float32)
+    t = torch.empty((n,), device=dev, dtype=torch.float32)
+    hit_g, nrm, hit_l = mk3(), mk3(), mk3()
+    new_dir = mk3() if want_phys else None
+    imult = torch.empty((n,), device=dev, dtype=torch.float32) if want_phys else None
+    if n:
+        dp = N.DeviceProgram.upload(prog, dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_surface_forward_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), n, n, N.ptr(dp.dev), dp.host_ptr, int(index),
+                N.ptr(t), N.ptr(hit_g), N.ptr(nrm), N.ptr(hit_l), N.ptr(new_dir), N.ptr(imult), n,
+                N.stream_handle(dev))
+        N.check(code, "rtt_surface_forward_f32")
+    out = dict(t=t, hit_global=hit_g.t(), normal_global=nrm.t(), hit_local=hit_l.t())
+    if want_phys:
+        out.update(new_dir=new_dir.t(), imult=imult)
+    return out
+
+
+def ray_cast(rays: Rays, prog: np.ndarray):
+    """winner [N] int32 (-1 = miss) and tmin [N]."""
+    n = _check_rays(rays)
+    dev = rays.device
+    winner = torch.full((n,), -1, device=dev, dtype=torch.int32)
+    tmin = torch.full((n,), float("inf"), device=dev, dtype=torch.float32)
+    if n and prog.shape[0]:
+        dp = N.DeviceProgram.upload(prog, dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_ray_cast_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n,
+                N.ptr(winner), N.ptr(tmin), N.stream_handle(dev))
+        N.check(code, "rtt_ray_cast_f32")
+    return winner, tmin
+
+
+def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bool = False):
+    """One Scene.step bounce on the device (in place by default)."""
+    n = _check_rays(rays)
+    if out is None:
+        out = rays
+    elif _check_rays(out) != n:
+        raise ValueError("`out` must hold the same number of rays")
+    dev = rays.device
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev)
+    winner = torch.full((n,), -1, device=dev, dtype=torch.int32) if want_winner else None
+    if n and prog.shape[0]:
+        dp = N.DeviceProgram.upload(prog, dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_step_nearest_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+                N.ptr(out._pos), N.ptr(out._dir), N.ptr(out.intensity), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(winner),
+                N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, N.stream_handle(dev))
+        N.check(code, "rtt_step_nearest_f32")
+    elif out is not rays:
+        out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
+    return winner, sens_hit, sens_w, sens_mask
+
+
+def apply_physics(rec: np.ndarray, hit_local, ray_dir, normal):
+    """One physics functor on [N,3] tensors -> (new_dir [N,3], imult [N])."""
+    N.require_device(hit_local, ray_dir, normal)
+    n = ray_dir.shape[0]
+    dev = ray_dir.device
+    planes = torch.stack([v.to(torch.float32).t() for v in (hit_local, ray_dir, normal)]).contiguous()
+    new_dir = torch.empty((3, n), device=dev, dtype=torch.float32)
+    imult = torch.empty((n,), device=dev, dtype=torch.float32)
+    if n:
+        dp = N.DeviceProgram.upload(np.asarray(rec).reshape(1), dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_apply_physics_f32(
+                N.ptr(planes[0]), N.ptr(planes[1]), N.ptr(planes[2]), n, n, N.ptr(dp.dev), dp.host_ptr,
+                N.ptr(new_dir), N.ptr(imult), N.stream_handle(dev))
+        N.check(code, "rtt_apply_physics_f32")
+    return new_dir.t(), imult
+
+
+def spot_moments(x, y, w, mask, pass_id: int, cx: float, cy: float, wsum: float, out: torch.Tensor):
+    """Accumulate spot-size moments into `out` (4 float64 on the device)."""
+    N.require_device(x, y, w, out)
+    n = x.numel()
+    if out.dtype != torch.float64 or out.numel() != 4:
+        raise ValueError("`out` must be 4 float64 values")
+    for t in (x, y, w):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError("x, y, w must be contiguous float32 tensors of equal length")
+    if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != n or not mask.is_contiguous()):
+        raise ValueError("mask must be a contiguous uint8 tensor of the same length")
+    if n:
+        with torch.cuda.device(x.device):
+            code = N.lib().rtt_spot_moments_f32(N.ptr(x), N.ptr(y), N.ptr(w), N.ptr(mask), n, int(pass_id),
+                                                float(cx), float(cy), float(wsum), N.ptr(out),
+                                                N.stream_handle(x.device))
+        N.check(code, "rtt_spot_moments_f32")
+    return out

@@ -1,0 +1,95 @@
+"""Optimisation goals on sensor hits (reference: optim/goals.py:99-187).
+
+``SpotSizeLoss`` = mean over bundles of  sum_i sqrt(((x_i-cx)^2 + (y_i-cy)^2) * w_i / W)  over hits
+with w_i > 0, W = sum w_i (clamped at 1e-12) and (cx, cy) the weighted centroid unless a target is
+given (optim/goals.py:165-183; the square root is inside the sum).  The sums are accumulated on
+the device in float64 by ``rtt_spot_moments_f32`` directly from the dense sensor records, so no
+per-hit tensors are materialised.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..elements import Sensor
+from ..rays.bundle import Bundle
+
+
+class Goal(nn.Module):
+    pass
+
+
+def spot_size_from_records(records, target_xy=None):
+    """records: iterable of (x [M], y [M], w [M], mask [M] uint8 or None) device tensors.
+    Returns (loss tensor [] float64 on the device, moments tensor [4]) or (None, None) when no
+    record holds a hit with w > 0."""
+    records = [r for r in records if r[0].numel() > 0]
+    if not records:
+        return None, None
+    dev = records[0][0].device
+    mom = torch.zeros(4, device=dev, dtype=torch.float64)
+    for x, y, w, m in records:
+        K.spot_moments(x, y, w, m, 0, 0.0, 0.0, 1.0, mom)
+    W, Sx, Sy, _ = mom.tolist()
+    if W <= 0.0:
+        return None, None
+    W = max(W, 1e-12)
+    if target_xy is None:
+        cx, cy = Sx / W, Sy / W
+    else:
+        cx, cy = float(target_xy[0]), float(target_xy[1])
+    for x, y, w, m in records:
+        K.spot_moments(x, y, w, m, 1, cx, cy, W, mom)
+    return mom[3], mom
+
+
+class SpotSizeLoss(Goal):
+
+    def __init__(self, sensor: Sensor, bundles: List[Bundle], N_rays: int = 128,
+                 target_xy: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.sensor = sensor
+        self.bundles = bundles
+        self.N_rays = N_rays
+        if target_xy is not None:
+            target_xy = torch.as_tensor(target_xy, dtype=torch.float32)
+            if target_xy.ndim == 1:
+                target_xy = target_xy.unsqueeze(0).expand(len(bundles), 2)
+        self._target_xy = target_xy
+
+    def _sensor_records(self):
+        s = self.sensor
+        recs = [(hit[0], hit[1], w, mask) for hit, w, mask, _ in s._dense]
+        for locs, w in zip(s._locs, s._inten):
+            recs.append((locs[:, 0].contiguous(), locs[:, 1].contiguous(), w.contiguous(), None))
+        return recs
+
+    def forward(self, scene) -> torch.Tensor:
+        from ..scene import SequentialScene
+        losses = []
+        for i, bundle in enumerate(self.bundles):
+            self.sensor.reset()
+            rays = bundle.sample(self.N_rays)
+            dev = next(iter(scene.parameters()), torch.zeros(1)).device
+            if dev.type != "cuda" and torch.cuda.is_available():
+                dev = torch.device("cuda", torch.cuda.current_device())
+            rays = rays.to(dev)
+            scene.rays = rays
+            if isinstance(scene, SequentialScene):
+                scene.simulate(rays)   # the reference's no-argument call only works on Scene
+            else:
+                scene.simulate()
+            recs = self._sensor_records()
+            if not recs:
+                r = scene.rays
+                recs = [(r._pos[0], r._pos[1], r.intensity, None)]
+            tgt = None
+            if self._target_xy is not None:
+                tgt = self._target_xy[min(i, self._target_xy.shape[0] - 1)]
+            loss, _ = spot_size_from_records(recs, tgt)
+            if loss is not None:
+                losses.append(loss)
+        if not losses:
+            return torch.tensor(0.0)
+        return torch.stack(losses).mean().to(torch.float32)

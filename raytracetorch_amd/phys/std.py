@@ -1,0 +1,60 @@
+"""Surface physics functors (reference: phys/std.py:8-254).
+
+A functor maps ``(hit_local, ray_dir, normal)`` to ``(new_dir, intensity_mult)``.  Inside a trace
+that mapping is evaluated by the kernels from the ``phys_kind`` / ``phys`` fields each functor
+writes into its surface record.  Calling a functor directly on ``[N,3]`` tensors runs the same
+device code through ``rtt_apply_physics_f32``.
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .. import program as P
+
+
+class SurfaceFunction(nn.Module):
+
+    _phys_kind = None
+
+    def _fill_physics(self, rec):
+        if self._phys_kind is None:
+            raise NotImplementedError(f"{type(self).__name__} has no kernel description")
+        rec["phys_kind"] = self._phys_kind
+
+    def forward(self, local_intersect, ray_dir, normal, **kwargs):
+        rec = P.new_record()
+        self._fill_physics(rec)
+        return K.apply_physics(rec, local_intersect, ray_dir, normal)
+
+
+class Transmit(SurfaceFunction):
+    """Direction unchanged, multiplier 1 (phys/std.py:221-235)."""
+    _phys_kind = P.PHYS_TRANSMIT
+
+
+class Block(SurfaceFunction):
+    """Absorber: direction and multiplier zero (phys/std.py:237-254)."""
+    _phys_kind = P.PHYS_BLOCK
+
+
+class Reflect(SurfaceFunction):
+    """d - 2 (d.n) n (phys/std.py:91-108)."""
+    _phys_kind = P.PHYS_REFLECT
+
+
+class RefractSnell(SurfaceFunction):
+    """Snell refraction with total internal reflection (phys/std.py:111-145).
+
+    `entering = d.n < 0`; the index ratio is `ior_out/ior_in` when entering and `ior_in/ior_out`
+    otherwise; the output is not re-normalised."""
+    _phys_kind = P.PHYS_SNELL
+
+    def __init__(self, ior_in, ior_out, ior_in_grad=False, ior_out_grad=False):
+        super().__init__()
+        self.ior_in = nn.Parameter(torch.as_tensor(ior_in, dtype=torch.float32), requires_grad=ior_in_grad)
+        self.ior_out = nn.Parameter(torch.as_tensor(ior_out, dtype=torch.float32), requires_grad=ior_out_grad)
+
+    def _fill_physics(self, rec):
+        rec["phys_kind"] = self._phys_kind
+        n_in, n_out = P.scalar(self.ior_in), P.scalar(self.ior_out)
+        rec["phys"][:] = (n_in, n_out, n_out / n_in, n_in / n_out)

@@ -1,0 +1,111 @@
+"""Scene compiler: flattens ``elements -> surfaces`` into the packed *surface program* the HIP
+kernels execute (one 256-byte ``RttSurface`` record per (element, surface); layout declared in
+``include/rtt_hip.h``).
+
+The reference walks its ``nn.Module`` tree once per surface visit from Python
+(scene/sequential.py:17-34, scene/base.py:164,213-226); here the tree is walked once per call on the
+host and everything per-ray happens inside one kernel.  Records are re-packed from the live
+``nn.Parameter`` values on every call; host copies of parameter values are cached by
+``(data_ptr, _version)`` so unchanged parameters cost no device synchronisation.
+"""
+import numpy as np
+import torch
+
+SURFACE_DTYPE = np.dtype([
+    ("surf_kind", "<i4"), ("bound_kind", "<i4"), ("shape_kind", "<i4"), ("phys_kind", "<i4"),
+    ("flags", "<i4"), ("element_id", "<i4"), ("surface_id", "<i4"), ("sensor_slot", "<i4"),
+    ("Rs", "<f4", (9,)), ("ts", "<f4", (3,)), ("Rj", "<f4", (9,)), ("tj", "<f4", (3,)),
+    ("geom", "<f4", (4,)), ("bnd", "<f4", (4,)), ("shp", "<f4", (8,)), ("phys", "<f4", (4,)),
+    ("pad", "<f4", (12,)),
+])
+RECORD_BYTES = SURFACE_DTYPE.itemsize
+assert RECORD_BYTES == 256
+MAX_SURFACES = 64
+
+# enum mirrors of include/rtt_hip.h
+SURF_PLANE, SURF_QUADRIC, SURF_QUADRIC_ZY, SURF_CYLINDER, SURF_SPHERE, SURF_CONE = range(6)
+(BND_NONE, BND_DISK, BND_RECT, BND_ELLIPSE, BND_HALF, BND_HALF_DISK, BND_SINGLE_CONE,
+ BND_ALWAYS) = range(8)
+SHP_NONE, SHP_SPHERIC_FACE, SHP_SPHERIC_EDGE, SHP_CYL_FACE, SHP_CYL_EDGE = range(5)
+PHYS_TRANSMIT, PHYS_BLOCK, PHYS_REFLECT, PHYS_SNELL, PHYS_APERTURE = range(5)
+F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR = 1, 2, 4, 8, 16
+
+_IDENTITY9 = np.eye(3, dtype=np.float32).reshape(9)
+f32 = np.float32
+
+_host_cache = {}
+
+
+def host_value(p) -> np.ndarray:
+    """float32 host copy of a (possibly device-resident) parameter / tensor / python number."""
+    if not isinstance(p, torch.Tensor):
+        return np.asarray(p, dtype=np.float32)
+    if p.device.type == "cpu":
+        return p.detach().to(torch.float32).numpy()
+    key = id(p)
+    tag = (p.data_ptr(), p._version)
+    hit = _host_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    v = p.detach().to(device="cpu", dtype=torch.float32).numpy()
+    if len(_host_cache) > 4096:
+        _host_cache.clear()
+    _host_cache[key] = (tag, v)
+    return v
+
+
+def scalar(p) -> np.float32:
+    return f32(host_value(p).reshape(-1)[0])
+
+
+def new_record() -> np.ndarray:
+    rec = np.zeros((), dtype=SURFACE_DTYPE)
+    rec["Rs"] = _IDENTITY9
+    rec["Rj"] = _IDENTITY9
+    rec["sensor_slot"] = -1
+    return rec
+
+
+def set_transform(rec, which: str, transform):
+    """Fill (R, t) of the element ('s') or surface ('j') frame from a RayTransform and set the
+    identity-rotation flag when R is bit-exactly the identity."""
+    R = host_value(transform.rot).reshape(9)
+    t = host_value(transform.trans).reshape(3)
+    rec["R" + which] = R
+    rec["t" + which] = t
+    if np.array_equal(R, _IDENTITY9):
+        rec["flags"] |= F_SHAPE_ROT_ID if which == "s" else F_SURF_ROT_ID
+
+
+def sag_f32(c, tz, r) -> np.float32:
+    """HalfSphere/HalfCyl.sagittalZ in float32, op for op (geom/bounded.py:129-139, :176-186)."""
+    c, tz, r = f32(c), f32(tz), f32(r)
+    r_sq = r * r
+    term = f32(1.0) - (c * c) * r_sq
+    term = term if term > 0 else f32(0.0)
+    denom = f32(1.0) + np.sqrt(term, dtype=np.float32)
+    return f32((c * r_sq) / denom + tz)
+
+
+def compile_elements(elements) -> np.ndarray:
+    """Records for every (element, surface) in scene order (scene/base.py:113-123)."""
+    recs = []
+    n_sensor = 0
+    for k, el in enumerate(elements):
+        for j in range(len(el.shape)):
+            rec = el._record(j)
+            rec["element_id"] = k
+            rec["surface_id"] = j
+            if int(rec["flags"]) & F_SENSOR:
+                rec["sensor_slot"] = n_sensor
+                n_sensor += 1
+            recs.append(rec)
+    if len(recs) > MAX_SURFACES:
+        raise ValueError(f"scene has {len(recs)} surfaces; the kernels accept at most {MAX_SURFACES}")
+    if not recs:
+        return np.zeros((0,), dtype=SURFACE_DTYPE)
+    return np.stack(recs)
+
+
+def n_sensor_slots(prog) -> int:
+    return int(((prog["flags"] & F_SENSOR) != 0).sum())

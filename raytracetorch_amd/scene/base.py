@@ -1,0 +1,142 @@
+"""Non-sequential ("naive") scene: every bounce, each ray goes to the nearest surface it hits
+(reference: scene/base.py:8-289).
+
+The reference materialises an [N, S] distance matrix, takes a row-min, then dispatches S masked
+sub-batches from Python.  Here one kernel per bounce keeps the running (t_min, winner) in
+registers while it loops over the packed surface program, then applies the winner's interaction.
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .. import program as P
+from ..elements import Element
+from ..rays import Bundle, Rays
+
+
+class Scene(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.elements = nn.ModuleList()
+        self.bundles = nn.ModuleList()
+        self._bundle_N_rays = []
+        self.rays = None
+        self.Nbounces = 100
+        self._build_index_maps()
+
+    # ---- population -----------------------------------------------------------------------------
+    def add_element(self, element: Element):
+        self.elements.append(element)
+
+    def add_bundle(self, bundle: Bundle, N_rays: int = 200):
+        self.bundles.append(bundle)
+        self._bundle_N_rays.append(N_rays)
+
+    def clear_elements(self):
+        self.elements = nn.ModuleList()
+        self._build_index_maps()
+
+    def clear_bundles(self):
+        self.bundles = nn.ModuleList()
+        self._bundle_N_rays = []
+        self.rays = None
+
+    def clear_rays(self):
+        self.rays = None
+
+    # ---- rays -----------------------------------------------------------------------------------
+    def _build_rays(self):
+        """Sample every bundle and concatenate (scene/base.py:57-90)."""
+        if len(self.bundles) == 0:
+            self.rays = None
+            return
+        parts = [b.sample(n) for b, n in zip(self.bundles, self._bundle_N_rays)]
+        if len(parts) == 1:
+            self.rays = parts[0]
+            return
+        self.rays = Rays.from_planes(
+            torch.cat([r._pos for r in parts], dim=1).contiguous(),
+            torch.cat([r._dir for r in parts], dim=1).contiguous(),
+            torch.cat([r.intensity for r in parts]), torch.cat([r.id for r in parts]),
+            torch.cat([r.wavelength for r in parts]))
+
+    # ---- surface bookkeeping ----------------------------------------------------------------------
+    def _build_index_maps(self):
+        """Global surface index -> (element index, surface index) (scene/base.py:96-123)."""
+        old = getattr(self, "map_to_element", None)
+        device = old.device if isinstance(old, torch.Tensor) else torch.device("cpu")
+        el, sf = [], []
+        for k, element in enumerate(self.elements):
+            n = len(element.shape)
+            el += [k] * n
+            sf += list(range(n))
+        self.register_buffer("map_to_element", torch.tensor(el, dtype=torch.long, device=device))
+        self.register_buffer("map_to_surface", torch.tensor(sf, dtype=torch.long, device=device))
+        self.total_surfaces = len(el)
+
+    def _program(self):
+        return P.compile_elements(self.elements)
+
+    def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask):
+        if sens_hit is None:
+            return
+        for rec in prog:
+            k = int(rec["sensor_slot"])
+            if k >= 0:
+                self.elements[int(rec["element_id"])]._record_dense(sens_hit[k], sens_w[k], sens_mask[k], rays.id)
+
+    # ---- simulation -------------------------------------------------------------------------------
+    def simulate(self):
+        """Up to `Nbounces` bounces of `self.rays` (scene/base.py:129-142)."""
+        if self.rays is None:
+            self._build_rays()
+        if self.rays is None:
+            return
+        self._build_index_maps()
+        for _ in range(self.Nbounces):
+            if not (self.rays.intensity > 0).any():
+                break
+            self.step()
+
+    def ray_cast(self, rays):
+        """(hit_mask [N], winner_element_ids [N], winner_surf_ids [N]) or None when nothing is hit
+        (scene/base.py:144-178)."""
+        if len(self.elements) == 0:
+            return None
+        raw = rays.unwrap() if hasattr(rays, "unwrap") else rays
+        winner, _ = K.ray_cast(raw, self._program())
+        hit = winner >= 0
+        if not hit.any():
+            return None
+        idx = winner.clamp_min(0).long()
+        if self.map_to_element.device != idx.device:
+            self._build_index_maps()
+            self.map_to_element = self.map_to_element.to(idx.device)
+            self.map_to_surface = self.map_to_surface.to(idx.device)
+        return hit, self.map_to_element[idx], self.map_to_surface[idx]
+
+    def step(self):
+        """One bounce for every ray that hits something and still carries intensity
+        (scene/base.py:180-235)."""
+        if self.rays is None or len(self.elements) == 0:
+            return
+        raw = self.rays.unwrap() if hasattr(self.rays, "unwrap") else self.rays
+        prog = self._program()
+        _, sens_hit, sens_w, sens_mask = K.step_nearest(raw, prog)
+        self._deliver_sensor_records(prog, raw, sens_hit, sens_w, sens_mask)
+
+    def compile_elements(self):
+        """The reference wraps elements in torch.compile here (scene/base.py:237-255); the HIP
+        path is already a single fused kernel per bounce, so this only refreshes the index maps."""
+        self._build_index_maps()
+
+    def to_sequential(self):
+        """Elements sorted by the z of their transform (scene/base.py:261-289)."""
+        from .sequential import SequentialScene
+        seq = SequentialScene(sorted(self.elements, key=lambda el: float(el.shape.transform.trans[2])))
+        seq.Nbounces = self.Nbounces
+        for b, n in zip(self.bundles, self._bundle_N_rays):
+            seq.add_bundle(b, n)
+        seq.rays = self.rays
+        return seq

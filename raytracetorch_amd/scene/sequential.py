@@ -1,0 +1,39 @@
+"""Fixed-order scene: rays visit every surface of every element in list order
+(reference: scene/sequential.py:6-105).
+
+``simulate(rays)`` is ONE kernel launch: each thread carries its ray through the whole surface
+program in registers, so HBM sees one read and one write of the ray state per trace instead of a
+gather / scatter per surface visit.
+"""
+import torch.nn as nn
+
+from .. import kernels as K
+from .base import Scene
+
+
+class SequentialScene(Scene):
+
+    def __init__(self, elements):
+        super().__init__()
+        self.elements = nn.ModuleList(elements)
+
+    def simulate(self, rays, out=None):
+        """Propagate `rays` through all surfaces; mutates and returns `rays` like the reference
+        (scene/sequential.py:12-36).  With `out` (a second Rays of the same size) the result goes
+        there and `rays` is left untouched."""
+        prog = self._program()
+        sens_hit, sens_w, sens_mask = K.trace_sequential(rays, prog, out=out)
+        self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask)
+        return rays if out is None else out
+
+    def to_base(self):
+        """scene/sequential.py:80-105."""
+        base = Scene()
+        base.Nbounces = self.Nbounces
+        for el in self.elements:
+            base.add_element(el)
+        for b, n in zip(self.bundles, self._bundle_N_rays):
+            base.add_bundle(b, n)
+        base.rays = self.rays
+        base._build_index_maps()
+        return base

@@ -1,0 +1,178 @@
+"""Scene builders shared by the golden-vector generator and the tests.
+
+Every builder takes a namespace `ns` exposing the reference's public class names
+(``SingletLens``, ``Sensor``, ``Disk``, ``RayTransform`` ...).  ``oracle/make_goldens.py`` passes a
+namespace built from the upstream reference, the tests pass one built from ``raytracetorch_amd``;
+constructor calls are therefore literally identical on both sides.
+"""
+import math
+import types
+
+import torch
+
+
+def namespace_from_package(pkg):
+    ns = types.SimpleNamespace()
+    for mod in (pkg.geom, pkg.phys, pkg.elements, pkg.scene, pkg.rays):
+        for k in dir(mod):
+            if not k.startswith("_"):
+                setattr(ns, k, getattr(mod, k))
+    for k in ("HalfSphere", "HalfCyl", "BoundedHalfSphere", "SingleCone"):
+        setattr(ns, k, getattr(pkg.geom.bounded, k))
+    ns.Cylinder = pkg.geom.primitives.Cylinder
+    ns.Cone = pkg.geom.primitives.Cone
+    ns.SpotSizeLoss = pkg.optim.goals.SpotSizeLoss
+    return ns
+
+
+def T(ns, z=0.0, x=0.0, y=0.0, rot=None):
+    return ns.RayTransform(translation=[x, y, z], rotation=rot)
+
+
+# ---------------------------------------------------------------------------------------------
+# ray sources (deterministic given the torch seed)
+# ---------------------------------------------------------------------------------------------
+def disk_bundle(ns, radius=4.0, z=-30.0, x=0.0, y=0.0, rot=None, ray_id=0):
+    return ns.CollimatedDisk(radius=radius, ray_id=ray_id,
+                             transform=ns.RayTransformBundle(translation=[x, y, z], rotation=rot))
+
+
+def gaussian_rays(ns, n, z=-10.0, spread=1.0, slope=0.1):
+    """C1 input: pos=(N(0,1), N(0,1), z), dir=normalize(slope*N, slope*N, 1)."""
+    pos = torch.randn(n, 3) * spread
+    pos[:, 2] = z
+    d = torch.randn(n, 3) * slope
+    d[:, 2] = 1.0
+    return ns.Rays.initialize(pos, d)
+
+
+# ---------------------------------------------------------------------------------------------
+# elements / systems
+# ---------------------------------------------------------------------------------------------
+def singlet(ns, **kw):
+    args = dict(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5, ior_media=1.0, inked=True)
+    args.update(kw)
+    return ns.SingletLens(**args)
+
+
+def system5(ns):
+    """C3: lens, stop, lens, mirror, sensor = 9 surfaces."""
+    return [
+        singlet(ns, transform=T(ns, 0.0)),
+        ns.CircularAperture(3.5, invert=True, transform=T(ns, 5.0)),
+        ns.SingletLens(c1=0.02, c2=-0.03, d=16.0, t=2.0, ior_glass=1.6, inked=True, transform=T(ns, 10.0)),
+        ns.SphericalMirror(c1=-0.01, d=0.0, diameter=30.0, transform=T(ns, 40.0)),
+        ns.Sensor(ns.Disk(20.0, transform=T(ns, 25.0))),
+    ]
+
+
+def naive32(ns):
+    """C4: 6 singlets + 2 cylindrical singlets + mirror + sensor = 32 surfaces."""
+    els = [ns.SingletLens(c1=0.03, c2=-0.02, d=12.0, t=2.0, ior_glass=1.5, inked=True,
+                          transform=T(ns, 8.0 * i)) for i in range(6)]
+    els += [ns.CylSingletLens(c1=0.02, c2=-0.02, height=14.0, width=14.0, t=2.0, ior_glass=1.5, inked=True,
+                              transform=T(ns, 50.0 + 8.0 * i)) for i in range(2)]
+    els.append(ns.SphericalMirror(c1=-0.01, d=0.0, diameter=30.0, transform=T(ns, 80.0)))
+    els.append(ns.Sensor(ns.Disk(20.0, transform=T(ns, 70.0))))
+    return els
+
+
+def spot_system(ns, grads=True):
+    """C5: trainable singlet + sensor near the back focal plane."""
+    lens = singlet(ns, c1_grad=grads, c2_grad=grads, t_grad=grads, ior_glass_grad=grads)
+    sensor = ns.Sensor(ns.Disk(6.0, transform=T(ns, 19.0)))
+    return lens, sensor
+
+
+# name -> (elements builder, rays builder, n_rays)
+def sequential_cases(ns):
+    hp = math.pi / 2
+    return {
+        "singlet": (lambda: [singlet(ns)], lambda n: disk_bundle(ns).sample(n), 4096),
+        "singlet_tilted_bundle": (lambda: [singlet(ns)],
+                                  lambda n: disk_bundle(ns, rot=[-0.087, 0.0, 0.0]).sample(n), 4096),
+        "singlet_decentred_bundle": (lambda: [singlet(ns)],
+                                     lambda n: disk_bundle(ns, radius=3.0, x=1.5, y=-2.5).sample(n), 4096),
+        "singlet_posed": (lambda: [singlet(ns, transform=T(ns, 2.0, x=0.3, y=-0.2, rot=[0.05, -0.03, 0.4]))],
+                          lambda n: disk_bundle(ns, radius=4.5).sample(n), 4096),
+        "singlet_plano": (lambda: [singlet(ns, c1=0.0, c2=-0.08)], lambda n: disk_bundle(ns).sample(n), 4096),
+        "singlet_clear_edge": (lambda: [singlet(ns, inked=False)],
+                               lambda n: disk_bundle(ns, radius=6.0, rot=[0.12, 0.0, 0.0], y=3.0).sample(n), 4096),
+        "singlet_tir": (lambda: [singlet(ns, c1=0.09, c2=-0.09, t=4.0, ior_glass=1.9)],
+                        lambda n: ns.PointSource(NA=0.95, ray_id=2, transform=ns.RayTransformBundle(
+                            translation=[0.0, 0.0, 0.0])).sample(n), 4096),
+        "singlet_sensor": (lambda: list(spot_system(ns, grads=False)), lambda n: disk_bundle(ns).sample(n), 4096),
+        "system5": (lambda: system5(ns), lambda n: disk_bundle(ns).sample(n), 4096),
+        "doublet": (lambda: [ns.DoubletLens(c1=0.04, c2=-0.03, c3=-0.01, d=12.0, t1=3.0, t2=1.5,
+                                            ior_glass1=1.5, ior_glass2=1.7, transform=T(ns, 1.0)),
+                             ns.Sensor(ns.Disk(10.0, transform=T(ns, 30.0)))],
+                    lambda n: disk_bundle(ns, radius=5.0, rot=[0.02, 0.03, 0.0]).sample(n), 4096),
+        "triplet": (lambda: [ns.TripletLens(c1=0.05, c2=-0.02, c3=0.01, c4=-0.04, d=12.0, t1=2.0, t2=1.0, t3=2.5,
+                                            ior_glass1=1.5, ior_glass2=1.65, ior_glass3=1.55)],
+                    lambda n: disk_bundle(ns, radius=5.5).sample(n), 2048),
+        "dead_rays": (lambda: [singlet(ns), ns.Sensor(ns.Disk(50.0, transform=T(ns, 12.0)))],
+                      lambda n: disk_bundle(ns, radius=6.5).sample(n), 2048),
+        "aperture_plain": (lambda: [ns.CircularAperture(2.0, invert=False, transform=T(ns, 1.0)),
+                                    ns.Sensor(ns.Disk(30.0, transform=T(ns, 6.0)))],
+                           lambda n: disk_bundle(ns).sample(n), 1024),
+        "aperture_invert": (lambda: [ns.CircularAperture(2.0, invert=True, transform=T(ns, 1.0)),
+                                     ns.RectangularAperture(1.5, 0.5, invert=True, transform=T(ns, 2.0, rot=[0.0, 0.0, 0.3])),
+                                     ns.EllipticAperture(1.2, 0.4, rot=0.5, invert=True, transform=T(ns, 3.0)),
+                                     ns.Sensor(ns.Disk(30.0, transform=T(ns, 6.0)))],
+                            lambda n: disk_bundle(ns).sample(n), 2048),
+        "mirrors": (lambda: [ns.ParabolicMirror(c1=-0.02, d=0.0, transform=T(ns, 20.0)),
+                             ns.CylindricalMirror(c1=0.03, d=0.0, transform=T(ns, -5.0, rot=[0.0, 0.1, 0.0])),
+                             ns.ParabolicMirrorXZ(c1=-0.01, d=0.0, transform=T(ns, 25.0))],
+                    lambda n: disk_bundle(ns, z=-2.0).sample(n), 2048),
+        "cyl_singlet": (lambda: [ns.CylSingletLens(c1=0.04, c2=-0.03, height=12.0, width=10.0, t=2.5,
+                                                   ior_glass=1.5, inked=False, transform=T(ns, 0.0, rot=[0.0, 0.0, 0.2]))],
+                        lambda n: disk_bundle(ns, radius=7.5, rot=[0.05, 0.02, 0.0]).sample(n), 4096),
+    }
+
+
+def primitive_cases(ns):
+    """Bare surfaces exercised through Surface.intersectTest / Surface.forward."""
+    hp = math.pi / 2
+    return {
+        "plane_c1": (lambda: ns.Plane(ns.RayTransform(translation=torch.zeros(3))),
+                     lambda: gaussian_rays(ns, 1024)),
+        "plane_posed": (lambda: ns.Plane(T(ns, 3.0, x=1.0, rot=[0.3, -0.2, 0.1])), lambda: gaussian_rays(ns, 512)),
+        "sphere": (lambda: ns.Sphere(radius=torch.tensor(10.0)), lambda: gaussian_rays(ns, 512, z=-20.0, spread=6.0)),
+        "cylinder": (lambda: ns.Cylinder(5.0, transform=T(ns, 0.0, rot=[hp, 0.0, 0.0])),
+                     lambda: gaussian_rays(ns, 512, z=-20.0, spread=4.0)),
+        "quadric_parabola": (lambda: ns.Quadric(c=torch.tensor(0.1), k=torch.tensor(-1.0)),
+                             lambda: gaussian_rays(ns, 512, spread=3.0)),
+        "quadric_hyperbola": (lambda: ns.Quadric(c=0.08, k=-2.5, transform=T(ns, 1.0)),
+                              lambda: gaussian_rays(ns, 512, spread=3.0, slope=0.3)),
+        "quadric_zy": (lambda: ns.QuadricZY(c=0.07, k=-0.5, transform=T(ns, 0.5, rot=[0.0, 0.0, 0.7])),
+                       lambda: gaussian_rays(ns, 512, spread=3.0, slope=0.2)),
+        "cone": (lambda: ns.Cone(slope=0.5, transform=T(ns, 2.0)), lambda: gaussian_rays(ns, 512, spread=3.0, slope=0.3)),
+        "single_cone": (lambda: ns.SingleCone(slope=-0.7, transform=T(ns, 2.0)),
+                        lambda: gaussian_rays(ns, 512, spread=3.0, slope=0.3)),
+        "half_sphere": (lambda: ns.HalfSphere(curvature=0.1, curvature_grad=False, transform=T(ns, -1.0)),
+                        lambda: gaussian_rays(ns, 512, spread=5.0, slope=0.4)),
+        "bounded_half_sphere": (lambda: ns.BoundedHalfSphere(curvature=-0.05, diameter=8.0, transform=T(ns, 4.0)),
+                                lambda: gaussian_rays(ns, 512, spread=3.0, slope=0.2)),
+        "half_cyl": (lambda: ns.HalfCyl(curvature=0.09, curvature_grad=False, transform=T(ns, 0.0)),
+                     lambda: gaussian_rays(ns, 512, spread=5.0, slope=0.4)),
+        "disk_inverted": (lambda: ns.Disk(1.0, invert=True, transform=T(ns, 0.0)), lambda: gaussian_rays(ns, 256)),
+        "rectangle": (lambda: ns.Rectangle(1.0, 0.5, transform=T(ns, 0.0, rot=[0.0, 0.0, 0.3])),
+                      lambda: gaussian_rays(ns, 256)),
+        "ellipse": (lambda: ns.Ellipse(1.5, 0.5, 0.4, transform=T(ns, 0.0)), lambda: gaussian_rays(ns, 256)),
+    }
+
+
+def kat_rays(ns):
+    """Known-answer inputs of the reference's tests/test_primitive.py."""
+    R = ns.Rays.initialize
+    return {
+        "kat_plane": (lambda: ns.Plane(ns.RayTransform(translation=torch.zeros(3))),
+                      lambda: R([[0, 0, -10], [1, 1, -5], [-2, -2, -10]], [[0, 0, 1]] * 3)),
+        "kat_sphere": (lambda: ns.Sphere(radius=torch.tensor(10.0)),
+                       lambda: R([[0, 0, 0], [0, 0, -20], [0, 15, 0]], [[0, 0, 1], [0, 0, 1], [0, 1, 0]])),
+        "kat_parabola": (lambda: ns.Quadric(c=torch.tensor(0.1), k=torch.tensor(-1.0)),
+                         lambda: R([[0, 2, -10], [0, 5, -10]], [[0, 0, 1], [0, 0, 1]])),
+        "kat_implicit": (lambda: ns.Quadric(c=torch.tensor(0.1), k=torch.tensor(0.0)),
+                         lambda: R([[0, 0, -20], [1, 1, -20], [5, 5, -20], [0.1, 8, -20]],
+                                   [[0, 0, 1], [0, 0, 1], [0, 0.1, 1], [0, 0.1, 1]])),
+    }
