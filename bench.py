@@ -1,0 +1,157 @@
+"""Benchmark of the sequential singlet-lens trace (the headline workload) on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one `SequentialScene.simulate` of the singlet scene over one resident bundle of `--rays`
+rays per GPU (default 64 * 2^20): one kernel launch that tests 3 surfaces per ray.  Rays are
+sharded across ranks (each rank owns its own bundle, seeded by rank); the trace has no exchange
+step, so there is no data-path collective and scaling is weak.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+BYTES_PER_RAY = 56             # read pos+dir+intensity (28 B) + write the same (28 B), surface-count independent
+SURFACES_TESTED = 3            # front cap, back cap, edge cylinder
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=64 * 2 ** 20, help="rays per GPU")
+    ap.add_argument("--cpu-rays", type=int, default=2 ** 22, help="rays of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def device_bundle(n, device, seed):
+    """CollimatedDisk(radius=4) at z=-30 along +z, generated on the device as [3,N] planes."""
+    import math
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    theta = torch.rand(n, device=device, generator=g) * (2 * math.pi)
+    r = torch.sqrt(torch.rand(n, device=device, generator=g) * 16.0)
+    pos = torch.empty((3, n), device=device)
+    torch.mul(r, torch.cos(theta), out=pos[0])
+    torch.mul(r, torch.sin(theta), out=pos[1])
+    pos[2].fill_(-30.0)
+    del theta, r
+    d = torch.zeros((3, n), device=device)
+    d[2].fill_(1.0)
+    return pos, d
+
+
+def cpu_baseline(n, scenes, ns):
+    """The CPU oracle (a torch-CPU port of the reference's per-ray arithmetic) on a bounded sample."""
+    import rtt_oracle as O
+    import raytracetorch_amd.program as P
+    prog = P.compile_elements([scenes.singlet(ns)])
+    pos, d = device_bundle(n, "cpu", 0)
+    pos, d = pos.t().contiguous(), d.t().contiguous()
+    inten = torch.ones(n)
+    times = []
+    with torch.no_grad():
+        O.trace_sequential(prog, pos[:65536], d[:65536], inten[:65536])
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.trace_sequential(prog, pos, d, inten)
+            times.append(time.perf_counter() - t0)
+    t = statistics.median(times)
+    return {"value": n * SURFACES_TESTED / t, "unit": "ray-surface intersections/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/rtt_oracle.py trace_sequential, singlet (3 surfaces), {n} rays, median of 3, "
+                      f"{t * 1e3:.0f} ms per trace"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import raytracetorch_amd as rta
+    import scenes
+    ns = scenes.namespace_from_package(rta)
+
+    n = a.rays
+    scene = ns.SequentialScene([scenes.singlet(ns)])
+    pos, d = device_bundle(n, dev, 1000 + rank)
+    mk = lambda p, q: ns.Rays.from_planes(p, q, torch.ones(n, device=dev), torch.zeros(n, device=dev, dtype=torch.int8),
+                                          torch.zeros(n, device=dev))
+    rays = mk(pos, d)
+    out = mk(torch.empty_like(pos), torch.empty_like(d))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        scene.simulate(rays, out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()
+        scene.simulate(rays, out=out)
+        e.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = statistics.mean(s.elapsed_time(e) for s, e in ev)
+    alive = int((out.intensity > 0).sum().item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / a.steps
+        value = world * n * SURFACES_TESTED / (elapsed / a.steps)
+        achieved = BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "ray-surface intersections/sec", "value": value, "unit": "ray-surface intersections/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "sequential singlet-lens trace (SingletLens c1=.05 c2=-.05 d=10 t=3 n=1.5 inked; "
+                                   "CollimatedDisk r=4 at z=-30), 3 surfaces tested per ray",
+                       "rays_per_gpu": n, "rays_total": world * n, "surfaces": SURFACES_TESTED,
+                       "parallelism": f"rays sharded over {world} GPU(s), no data-path collective",
+                       "alive_after_trace_rank0": alive},
+            "rays_per_s": world * n / (elapsed / a.steps),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_trace_seq",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": BYTES_PER_RAY * n},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_rays, scenes, ns)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,40 +12,57 @@ def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
-def rel_err(a, b):
-    """Largest relative deviation of `a` from `b` over entries finite in both.
+def ray_err(a, b):
+    """Per-entry relative deviation of `a` from `b`; NaN where either side is not finite.
 
     [N] arrays: |a-b| / max(1, |b|).  [N,3] arrays (positions, directions, normals): per ray
     max_c |a-b| / max(1, ||b||_2), i.e. relative to the length of the reference vector."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     if a.shape != b.shape:
         raise AssertionError(f"shape mismatch {a.shape} vs {b.shape}")
-    if a.size == 0:
-        return 0.0
-    if a.ndim == 2 and a.shape[1] == 3:
-        fin = np.isfinite(a).all(1) & np.isfinite(b).all(1)
-        if not fin.any():
-            return 0.0
-        a, b = a[fin], b[fin]
-        return float(np.max(np.abs(a - b).max(1) / np.maximum(1.0, np.linalg.norm(b, axis=1))))
-    fin = np.isfinite(a) & np.isfinite(b)
-    if not fin.any():
-        return 0.0
-    return float(np.max(np.abs(a[fin] - b[fin]) / np.maximum(1.0, np.abs(b[fin]))))
+    with np.errstate(invalid="ignore"):
+        if a.ndim == 2 and a.shape[1] == 3:
+            fin = np.isfinite(a).all(1) & np.isfinite(b).all(1)
+            e = np.abs(a - b).max(1) / np.maximum(1.0, np.linalg.norm(b, axis=1))
+        else:
+            fin = np.isfinite(a) & np.isfinite(b)
+            e = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    return np.where(fin, e, np.nan)
+
+
+def rel_err(a, b):
+    e = ray_err(a, b)
+    return 0.0 if e.size == 0 or np.isnan(e).all() else float(np.nanmax(e))
 
 
 # Relative tolerance of the parity contract (float32 results vs the reference's float32 CPU path).
 PARITY_TOL = 1e-5
-# Cases whose *reference* float32 result already sits further than that from its own float64
-# evaluation (grazing hits on a paraboloid amplify one-ulp input differences); measured
-# reference-fp32 vs fp64: 6.5e-5 relative on positions.
-# Likewise a lens rotated about all three axes seen from 32 units away: reference-fp32 vs fp64 is
-# 1.1e-5 on the first-surface hit positions.
-LOOSE_CASES = {"mirrors": 1e-4, "singlet_posed": 3e-5}
 
 
-def tol_for(name):
-    return LOOSE_CASES.get(name, PARITY_TOL)
+def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what=""):
+    """`got` agrees with the reference's float32 result `ref` within `tol` on every ray.
+
+    Two correct float32 evaluations can differ by more than that on ill-conditioned rays: the
+    reference's torch-CPU sqrt (MKL VML) is not correctly rounded while gfx950's is, and one ulp
+    under a cancelling `-B - sqrt(disc)` is amplified a hundredfold (a paraxial ray on a paraboloid
+    shows 3e-5 in t).  When a float64 evaluation `truth` of the same formulas is supplied, such a
+    case is accepted if `got` is no further from `truth` than twice the reference's own deviation
+    from it, both at the worst ray and at the 99th percentile."""
+    e = ray_err(got, ref)
+    if e.size == 0 or np.isnan(e).all():
+        return
+    worst = float(np.nanmax(e))
+    if worst < tol:
+        return
+    assert truth is not None, f"{what}: deviates from the reference by {worst:.3g} (> {tol})"
+    frac = float(np.nanmean(e >= tol))
+    eg, er = ray_err(got, truth), ray_err(ref, truth)
+    both = ~np.isnan(eg) & ~np.isnan(er)
+    wg, wr = float(eg[both].max()), float(er[both].max())
+    pg, pr = float(np.percentile(eg[both], 99)), float(np.percentile(er[both], 99))
+    assert wg <= 2.0 * wr + 1e-6 and pg <= 2.0 * pr + 1e-6, (
+        f"{what}: {frac:.2%} of rays deviate from the reference by more than {tol} (worst {worst:.3g}); "
+        f"vs float64 worst/p99: ours {wg:.3g}/{pg:.3g}, reference {wr:.3g}/{pr:.3g}")
 
 
 def pattern_mismatch(a, b):
