@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--rays", type=int, default=64 * 2 ** 20, help="rays per GPU")
     ap.add_argument("--cpu-rays", type=int, default=2 ** 22, help="rays of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
+    ap.add_argument("--tune-blocks", type=int, default=0, help="override the grid cap for experiments")
     return ap.parse_args()
 
 
@@ -95,6 +97,12 @@ def main():
     import raytracetorch_amd as rta
     import scenes
     ns = scenes.namespace_from_package(rta)
+
+    from raytracetorch_amd import _native
+    if a.tune_rpt:
+        _native.check(_native.lib().rtt_tune(0, a.tune_rpt), "rtt_tune")
+    if a.tune_blocks:
+        _native.check(_native.lib().rtt_tune(1, a.tune_blocks), "rtt_tune")
 
     n = a.rays
     scene = ns.SequentialScene([scenes.singlet(ns)])

@@ -33,7 +33,7 @@ _SIGNATURES = {
     "rtt_apply_physics_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "rtt_spot_moments_f32": [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _dbl, _dbl, _vp, _vp],
 }
-EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes")
+EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune")
 
 
 class NativeLibraryError(RuntimeError):
@@ -60,6 +60,8 @@ def lib():
     L.rtt_strerror.argtypes = [_int]
     L.rtt_strerror.restype = ctypes.c_char_p
     L.rtt_abi_version.restype = _int
+    L.rtt_tune.argtypes = [_int, _int]
+    L.rtt_tune.restype = _int
     L.rtt_surface_record_bytes.restype = _int
     if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
         raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")

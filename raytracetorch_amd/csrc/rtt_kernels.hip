@@ -1,18 +1,27 @@
 // rtt_kernels.hip — gfx950 (MI355X / CDNA4) kernels and C ABI of the RayTraceTorch ray-propagation path.
 //
 // Execution model
-//   * one lane = one ray; the ray state (pos, dir, intensity: 7 floats) stays in VGPRs for the whole
-//     surface program, so HBM sees 28 B in + 28 B out per ray per trace regardless of surface count;
-//   * ray storage is structure-of-arrays, a wavefront reads/writes 256 contiguous bytes per component;
+//   * one lane = one ray, or two adjacent rays held in packed registers (v_pk_*_f32); the ray state
+//     (pos, dir, intensity: 7 floats) stays in VGPRs for the whole surface program, so HBM sees
+//     28 B in + 28 B out per ray per trace regardless of surface count;
+//   * ray storage is structure-of-arrays, a wavefront reads/writes 256 or 512 contiguous bytes per
+//     component and instruction;
 //   * the surface loop is wave-uniform: record `s` is addressed with a scalar index, so its fields come
 //     in through scalar loads (SGPRs) and the `switch` on kinds is a scalar branch — no divergence in
 //     the sequential trace.  In the nearest-hit step, lanes that won different surfaces are served by
 //     a readfirstlane waterfall so the record stays scalar there as well;
 //   * no MFMA: the work is elementwise geometry (a few hundred flops per 56 B), HBM-bound.
 //
-// Numerics follow the reference's float32 torch-CPU evaluation order (cited per function, paths
-// relative to the reference tree); the file is built with -ffp-contract=off so no product-sum is
-// fused, and hipcc's default correctly-rounded fp32 divide / sqrt is kept.
+// Numerics follow the reference's float32 torch-CPU formulas (cited per function, paths relative to
+// the reference tree).  Two builds of the same source:
+//   default            product-sums may contract to FMA and normalisations / quotients use the hardware
+//                      reciprocal, reciprocal-sqrt and sqrt (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32, <= 1 ulp
+//                      each), except the square root of the discriminant, which stays correctly rounded
+//                      — the kernel is otherwise VALU-bound on divide/sqrt expansions (~10 instructions each);
+//   -DRTT_STRICT_FP=1  (with -ffp-contract=off) keeps the reference's operation order with
+//                      correctly-rounded divide and sqrt; used to separate rounding from logic when
+//                      a parity test moves.
+// Every discrete decision (hit / miss, bounds, TIR, entering) uses the same comparisons in both.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,320 +33,493 @@ constexpr float kInf = __builtin_huge_valf();
 constexpr float kEps = 1e-6f;  // geom/primitives.py:6 and :21
 constexpr int kBlock = 256;
 
+#ifndef RTT_STRICT_FP
+#define RTT_STRICT_FP 0
+#endif
+constexpr bool kStrict = RTT_STRICT_FP != 0;
+
+// ------------------------------------------------------------------------------------------------
+// Lane types.  All per-ray arithmetic is written once over a lane type T: `float` (one ray per lane)
+// or `f2` (two rays per lane).  The f32 vector ALU of gfx950 retires a wave64 mul / add / fma in four
+// cycles whether it is scalar or packed, so carrying two rays per lane in v_pk_{mul,add,fma}_f32
+// halves the cost of most of the arithmetic; compares, selects and the transcendental units stay
+// per component.  Masks are `bool` for float and an int vector (-1 / 0 per component) for f2.
+// ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+template <class T> struct LaneOf;
+template <> struct LaneOf<float> { using M = bool; static constexpr int N = 1; };
+template <> struct LaneOf<f2> { using M = i2; static constexpr int N = 2; };
+
+#define DI __device__ __forceinline__
+DI bool lt(float a, float b) { return a < b; }
+DI i2 lt(f2 a, f2 b) { return a < b; }
+DI bool le(float a, float b) { return a <= b; }
+DI i2 le(f2 a, f2 b) { return a <= b; }
+DI bool ge(float a, float b) { return a >= b; }
+DI i2 ge(f2 a, f2 b) { return a >= b; }
+DI bool gt(float a, float b) { return a > b; }
+DI i2 gt(f2 a, f2 b) { return a > b; }
+DI bool isnan_(float a) { return a != a; }
+DI i2 isnan_(f2 a) { return a != a; }
+DI bool and_(bool a, bool b) { return a && b; }
+DI i2 and_(i2 a, i2 b) { return a & b; }
+DI bool or_(bool a, bool b) { return a || b; }
+DI i2 or_(i2 a, i2 b) { return a | b; }
+DI bool not_(bool a) { return !a; }
+DI i2 not_(i2 a) { return ~a; }
+DI bool any_(bool a) { return a; }
+DI bool any_(i2 a) { return (a.x | a.y) != 0; }
+DI float sel(bool m, float a, float b) { return m ? a : b; }
+DI f2 sel(i2 m, f2 a, f2 b) { return m ? a : b; }
+DI float abs_(float a) { return fabsf(a); }
+DI f2 abs_(f2 a) { return __builtin_elementwise_abs(a); }
+DI float max_(float a, float b) { return fmaxf(a, b); }
+DI f2 max_(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+DI float min_(float a, float b) { return fminf(a, b); }
+DI f2 min_(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+DI float sqrt_ieee(float a) { return sqrtf(a); }
+DI f2 sqrt_ieee(f2 a) { return f2{sqrtf(a.x), sqrtf(a.y)}; }
+DI float div_ieee(float a, float b) { return a / b; }
+DI f2 div_ieee(f2 a, f2 b) { return a / b; }
+// 1/x, 1/sqrt(x), sqrt(x): hardware approximations (<= 1 ulp) unless the strict build is selected.
+DI float rcp_(float x) { return kStrict ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
+DI f2 rcp_(f2 x) { return f2{rcp_(x.x), rcp_(x.y)}; }
+DI float sqrt_(float x) { return kStrict ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
+DI f2 sqrt_(f2 x) { return f2{sqrt_(x.x), sqrt_(x.y)}; }
+DI float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+DI f2 rsq_(f2 x) { return f2{rsq_(x.x), rsq_(x.y)}; }
+DI float quot(float a, float b) { return kStrict ? a / b : a * rcp_(b); }
+DI f2 quot(f2 a, f2 b) { return kStrict ? a / b : a * rcp_(b); }
+template <class T> DI T splat(float v) { return T(v); }
+DI float comp(float a, int) { return a; }
+DI float comp(f2 a, int k) { return k == 0 ? a.x : a.y; }
+DI bool mcomp(bool m, int) { return m; }
+DI bool mcomp(i2 m, int k) { return (k == 0 ? m.x : m.y) != 0; }
+
+template <class T>
 struct V3 {
-  float x, y, z;
+  T x, y, z;
 };
 
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> DI V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> DI V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> DI V3<T> scale(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class T> DI T dot3(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T, class M> DI V3<T> sel3(M m, V3<T> a, V3<T> b) { return {sel(m, a.x, b.x), sel(m, a.y, b.y), sel(m, a.z, b.z)}; }
+
+// ------------------------------------------------------------------------------------------------
+// Visit configurations.  A surface visit is written once, as templates over a configuration C that
+// answers "which geometry / bound / shape bound / physics is this record?".  The generic
+// configuration reads the kinds from the record (scalar registers, scalar branches); specialised
+// configurations fix them at compile time so that the commonest visits (lens face + Snell, lens edge,
+// bounded plane, mirror cap, ...) become straight-line vector code with a handful of scalar
+// instructions.  The host picks the configuration per record (classify(), below); a record that
+// matches none runs the generic one, so specialisation never changes what is computed.
+// ------------------------------------------------------------------------------------------------
+constexpr int DYN = -1;
+
+template <int SK, int BK, int HK, int PK, bool ROT_ID>
+struct Cfg {
+  static __device__ __forceinline__ int sk(const RttSurface& S) { return SK == DYN ? S.surf_kind : SK; }
+  static __device__ __forceinline__ int bk(const RttSurface& S) { return BK == DYN ? S.bound_kind : BK; }
+  static __device__ __forceinline__ int hk(const RttSurface& S) { return HK == DYN ? S.shape_kind : HK; }
+  static __device__ __forceinline__ int pk(const RttSurface& S) { return PK == DYN ? S.phys_kind : PK; }
+  static __device__ __forceinline__ bool has_shape(const RttSurface& S) {
+    return HK == DYN ? (S.flags & RTT_F_HAS_SHAPE) != 0 : HK != RTT_SHP_NONE;
+  }
+  static __device__ __forceinline__ bool rs_id(const RttSurface& S) {
+    return ROT_ID ? true : (S.flags & RTT_F_SHAPE_ROT_ID) != 0;
+  }
+  static __device__ __forceinline__ bool rj_id(const RttSurface& S) {
+    return ROT_ID ? true : (S.flags & RTT_F_SURF_ROT_ID) != 0;
+  }
+};
+
+using CGeneric = Cfg<DYN, DYN, DYN, DYN, false>;
+// spherical / conic lens face of a Spheric stack, unrotated element, Snell refraction
+using CFaceSnell = Cfg<RTT_SURF_QUADRIC, RTT_BND_HALF, RTT_SHP_SPHERIC_FACE, RTT_PHYS_SNELL, true>;
+// cylindrical lens edge of a Spheric stack, inked (Block) or clear (Snell)
+using CEdgeBlock = Cfg<RTT_SURF_CYLINDER, RTT_BND_NONE, RTT_SHP_SPHERIC_EDGE, RTT_PHYS_BLOCK, true>;
+using CEdgeSnell = Cfg<RTT_SURF_CYLINDER, RTT_BND_NONE, RTT_SHP_SPHERIC_EDGE, RTT_PHYS_SNELL, true>;
+// bare disk-bounded plane: sensors (Transmit) and circular stops (ApertureFilter)
+using CDiskPlane = Cfg<RTT_SURF_PLANE, RTT_BND_DISK, RTT_SHP_NONE, DYN, true>;
+// bare spherical mirror cap
+using CMirrorCap = Cfg<RTT_SURF_QUADRIC, RTT_BND_HALF_DISK, RTT_SHP_NONE, RTT_PHYS_REFLECT, true>;
+// cylindrical lens: curved faces (unrotated) and the four side planes (rotated by +-90 degrees)
+using CCylFaceSnell = Cfg<RTT_SURF_QUADRIC_ZY, RTT_BND_HALF, RTT_SHP_CYL_FACE, RTT_PHYS_SNELL, true>;
+using CCylSide = Cfg<RTT_SURF_PLANE, RTT_BND_NONE, RTT_SHP_CYL_EDGE, DYN, false>;
+
+enum { OP_GENERIC = 0, OP_FACE_SNELL, OP_EDGE_BLOCK, OP_EDGE_SNELL, OP_DISK_PLANE, OP_MIRROR_CAP, OP_CYL_FACE_SNELL,
+       OP_CYL_SIDE, OP_COUNT };
+
+// one opcode byte per surface, passed by value as a kernel argument (scalar loads)
+struct Ops {
+  uint32_t w[RTT_MAX_SURFACES / 4];
+};
+
+__device__ __forceinline__ int op_of(const Ops& ops, int s) { return (ops.w[s >> 2] >> ((s & 3) * 8)) & 0xff; }
+
+#define RTT_DISPATCH(op, CALL)          \
+  switch (op) {                         \
+    case OP_FACE_SNELL: CALL(CFaceSnell); break;       \
+    case OP_EDGE_BLOCK: CALL(CEdgeBlock); break;       \
+    case OP_EDGE_SNELL: CALL(CEdgeSnell); break;       \
+    case OP_DISK_PLANE: CALL(CDiskPlane); break;       \
+    case OP_MIRROR_CAP: CALL(CMirrorCap); break;       \
+    case OP_CYL_FACE_SNELL: CALL(CCylFaceSnell); break; \
+    case OP_CYL_SIDE: CALL(CCylSide); break;           \
+    default: CALL(CGeneric); break;                    \
+  }
 
 // v @ R, R row-major (geom/transform.py:92-93).  `ident` skips the products: with R exactly the
 // identity x*1 + y*0 + z*0 == x bit for bit for finite inputs.
-__device__ __forceinline__ V3 rowmat(V3 v, const float* R, bool ident) {
+template <class T>
+DI V3<T> rowmat(V3<T> v, const float* R, bool ident) {
   if (ident) return v;
   return {v.x * R[0] + v.y * R[3] + v.z * R[6], v.x * R[1] + v.y * R[4] + v.z * R[7],
           v.x * R[2] + v.y * R[5] + v.z * R[8]};
 }
 
 // v @ R^T (geom/primitives.py:94, geom/shape.py:85)
-__device__ __forceinline__ V3 rowmat_t(V3 v, const float* R, bool ident) {
+template <class T>
+DI V3<T> rowmat_t(V3<T> v, const float* R, bool ident) {
   if (ident) return v;
   return {v.x * R[0] + v.y * R[1] + v.z * R[2], v.x * R[3] + v.y * R[4] + v.z * R[5],
           v.x * R[6] + v.y * R[7] + v.z * R[8]};
 }
 
 // torch.min over a stacked dim propagates NaN (geom/primitives.py:34, geom/bounded.py:34)
-__device__ __forceinline__ float nanmin(float a, float b) {
-  if (a != a) return a;
-  if (b != b) return b;
-  return a < b ? a : b;
+template <class T>
+DI T nanmin(T a, T b) {
+  return sel(or_(isnan_(a), isnan_(b)), splat<T>(__builtin_nanf("")), min_(a, b));
 }
 
+template <class T>
 struct Frames {
-  V3 pe, de;  // element frame (de un-normalised, geom/shape.py:47)
-  V3 pl, dl;  // surface frame
+  V3<T> pe, de;  // element frame (de un-normalised, geom/shape.py:47)
+  V3<T> pl, dl;  // surface frame
 };
 
 // Global -> element frame (+ re-normalisation, rays/ray.py:22-25 via with_coords :84-97)
 // -> surface frame (geom/shape.py:37-38, geom/primitives.py:50, geom/transform.py:90-93).
-__device__ __forceinline__ Frames to_frames(const RttSurface& S, V3 p, V3 d) {
-  Frames f;
-  V3 den;
-  if (S.flags & RTT_F_HAS_SHAPE) {
-    const bool id = S.flags & RTT_F_SHAPE_ROT_ID;
-    V3 ts = {S.ts[0], S.ts[1], S.ts[2]};
+template <class C, class T>
+DI Frames<T> to_frames(const RttSurface& S, V3<T> p, V3<T> d) {
+  Frames<T> f;
+  V3<T> den;
+  if (C::has_shape(S)) {
+    const bool id = C::rs_id(S);
+    V3<T> ts = {splat<T>(S.ts[0]), splat<T>(S.ts[1]), splat<T>(S.ts[2])};
     f.pe = rowmat(p - ts, S.Rs, id);
     f.de = rowmat(d, S.Rs, id);
-    float n = sqrtf(f.de.x * f.de.x + f.de.y * f.de.y + f.de.z * f.de.z);
-    n = fmaxf(n, 1e-12f);
-    den = {f.de.x / n, f.de.y / n, f.de.z / n};
+    const T n2 = f.de.x * f.de.x + f.de.y * f.de.y + f.de.z * f.de.z;
+    if (kStrict) {
+      const T n = max_(sqrt_ieee(n2), splat<T>(1e-12f));
+      den = {div_ieee(f.de.x, n), div_ieee(f.de.y, n), div_ieee(f.de.z, n)};
+    } else {
+      // de / max(|de|, 1e-12) == de * rsqrt(max(|de|^2, 1e-24))
+      den = scale(rsq_(max_(n2, splat<T>(1e-24f))), f.de);
+    }
   } else {
     f.pe = p;
     f.de = d;
     den = d;
   }
-  const bool idj = S.flags & RTT_F_SURF_ROT_ID;
-  V3 tj = {S.tj[0], S.tj[1], S.tj[2]};
+  const bool idj = C::rj_id(S);
+  V3<T> tj = {splat<T>(S.tj[0]), splat<T>(S.tj[1]), splat<T>(S.tj[2])};
   f.pl = rowmat(f.pe - tj, S.Rj, idj);
   f.dl = rowmat(den, S.Rj, idj);
   return f;
 }
 
 // Quadric._solve_quadratic (geom/primitives.py:290-320) and the Cone variant (:436-466).
-template <bool ABS_DISC>
-__device__ __forceinline__ void quadratic_with_linear_fallback(float A, float B, float C, float& t1, float& t2) {
-  const float disc = B * B - 4.0f * A * C;
-  const bool hit = disc >= 0.0f;
-  const bool lin = fabsf(A) < kEps;
-  const float sq = ABS_DISC ? sqrtf(fabsf(disc)) : sqrtf(hit ? disc : 0.0f);
-  const float A_safe = lin ? 1.0f : A;
-  const float den = 2.0f * A_safe;
-  t1 = (-B - sq) / den;
-  t2 = (-B + sq) / den;
-  t1 = hit ? t1 : kInf;
-  t2 = hit ? t2 : kInf;
-  if (lin) {
-    const float B_safe = fabsf(B) < kEps ? kEps : B;
-    t1 = t2 = -C / B_safe;
+template <bool ABS_DISC, class T>
+DI void quadratic_with_linear_fallback(T A, T B, T Cc, T& t1, T& t2) {
+  const T inf = splat<T>(kInf), eps = splat<T>(kEps);
+  const T disc = B * B - 4.0f * A * Cc;
+  const auto hit = ge(disc, splat<T>(0.0f));
+  const auto lin = lt(abs_(A), eps);
+  // correctly rounded in both builds: the root -B - sqrt(disc) cancels for near-paraxial rays and
+  // amplifies every ulp of the square root
+  const T sq = ABS_DISC ? sqrt_ieee(abs_(disc)) : sqrt_ieee(sel(hit, disc, splat<T>(0.0f)));
+  const T A_safe = sel(lin, splat<T>(1.0f), A);
+  const T den = 2.0f * A_safe;
+  if (kStrict) {
+    t1 = div_ieee(-B - sq, den);
+    t2 = div_ieee(-B + sq, den);
+  } else {
+    const T r = rcp_(den);
+    t1 = (-B - sq) * r;
+    t2 = (-B + sq) * r;
+  }
+  t1 = sel(hit, t1, inf);
+  t2 = sel(hit, t2, inf);
+  if (any_(lin)) {
+    const T B_safe = sel(lt(abs_(B), eps), eps, B);
+    const T tl = quot(-Cc, B_safe);
+    t1 = sel(lin, tl, t1);
+    t2 = sel(lin, tl, t2);
   }
 }
 
 // _solve_t of each primitive in the surface frame.  Returns the number of roots (1 or 2).
-__device__ __forceinline__ int solve_roots(const RttSurface& S, V3 o, V3 d, float& t1, float& t2) {
-  switch (S.surf_kind) {
+template <class C, class T>
+DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2) {
+  const T inf = splat<T>(kInf), zero = splat<T>(0.0f);
+  switch (C::sk(S)) {
     case RTT_SURF_PLANE: {  // geom/primitives.py:124-136
-      const float safe = fabsf(d.z) < kEps ? 1e-8f : d.z;
-      t1 = -o.z / safe;
+      const T safe = sel(lt(abs_(d.z), splat<T>(kEps)), splat<T>(1e-8f), d.z);
+      t1 = quot(-o.z, safe);
       t2 = t1;
       return 1;
     }
     case RTT_SURF_SPHERE: {  // geom/primitives.py:155-181
-      const float b = 2.0f * dot3(o, d);
-      const float c = dot3(o, o) - S.geom[1];
-      const float disc = b * b - 4.0f * c;
-      const bool hit = disc >= 0.0f;
-      const float sq = sqrtf(hit ? disc : 0.0f);
-      t1 = hit ? (-b - sq) / 2.0f : kInf;
-      t2 = hit ? (-b + sq) / 2.0f : kInf;
+      const T b = 2.0f * dot3(o, d);
+      const T c = dot3(o, o) - S.geom[1];
+      const T disc = b * b - 4.0f * c;
+      const auto hit = ge(disc, zero);
+      const T sq = sqrt_ieee(sel(hit, disc, zero));
+      t1 = sel(hit, (-b - sq) * 0.5f, inf);
+      t2 = sel(hit, (-b + sq) * 0.5f, inf);
       return 2;
     }
     case RTT_SURF_CYLINDER: {  // geom/primitives.py:201-231
-      const float A = d.x * d.x + d.y * d.y;
-      const float B = 2.0f * (o.x * d.x + o.y * d.y);
-      const float C = (o.x * o.x + o.y * o.y) - S.geom[1];
-      const float disc = B * B - 4.0f * A * C;
-      const bool hit = disc >= 0.0f;
-      const float sq = sqrtf(fabsf(disc));
-      const float den = 2.0f * A;
-      t1 = hit ? (-B - sq) / den : kInf;
-      t2 = hit ? (-B + sq) / den : kInf;
+      const T A = d.x * d.x + d.y * d.y;
+      const T B = 2.0f * (o.x * d.x + o.y * d.y);
+      const T Cc = (o.x * o.x + o.y * o.y) - S.geom[1];
+      const T disc = B * B - 4.0f * A * Cc;
+      const auto hit = ge(disc, zero);
+      const T sq = sqrt_ieee(abs_(disc));
+      const T den = 2.0f * A;
+      // A == 0 gives 1/den = inf; (-B -+ sq) * inf is inf or NaN exactly as the quotient by zero is
+      t1 = sel(hit, quot(-B - sq, den), inf);
+      t2 = sel(hit, quot(-B + sq, den), inf);
       return 2;
     }
     case RTT_SURF_QUADRIC: {  // geom/primitives.py:266-288
       const float c = S.geom[0], c1k = S.geom[2];
       const float two_c = 2.0f * c, two_c1k = 2.0f * c1k;
-      const float A = c * (d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
-      const float B = two_c * (o.x * d.x + o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
-      const float C = c * (o.x * o.x + o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
-      quadratic_with_linear_fallback<true>(A, B, C, t1, t2);
+      const T A = c * (d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
+      const T B = two_c * (o.x * d.x + o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
+      const T Cc = c * (o.x * o.x + o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
+      quadratic_with_linear_fallback<true>(A, B, Cc, t1, t2);
       return 2;
     }
     case RTT_SURF_QUADRIC_ZY: {  // geom/primitives.py:356-377
       const float c = S.geom[0], c1k = S.geom[2];
       const float two_c = 2.0f * c, two_c1k = 2.0f * c1k;
-      const float A = c * (d.y * d.y) + c1k * (d.z * d.z);
-      const float B = two_c * (o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
-      const float C = c * (o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
-      quadratic_with_linear_fallback<true>(A, B, C, t1, t2);
+      const T A = c * (d.y * d.y) + c1k * (d.z * d.z);
+      const T B = two_c * (o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
+      const T Cc = c * (o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
+      quadratic_with_linear_fallback<true>(A, B, Cc, t1, t2);
       return 2;
     }
     default: {  // RTT_SURF_CONE, geom/primitives.py:416-466
       const float k2 = S.geom[1];
-      const float A = d.z * d.z - k2 * (d.x * d.x + d.y * d.y);
-      const float B = 2.0f * (o.z * d.z - k2 * (o.x * d.x + o.y * d.y));
-      const float C = o.z * o.z - k2 * (o.x * o.x + o.y * o.y);
-      quadratic_with_linear_fallback<false>(A, B, C, t1, t2);
+      const T A = d.z * d.z - k2 * (d.x * d.x + d.y * d.y);
+      const T B = 2.0f * (o.z * d.z - k2 * (o.x * d.x + o.y * d.y));
+      const T Cc = o.z * o.z - k2 * (o.x * o.x + o.y * o.y);
+      quadratic_with_linear_fallback<false>(A, B, Cc, t1, t2);
       return 2;
     }
   }
 }
 
 // SurfaceBounded.inBounds variants in the surface frame, without `invert` (geom/bounded.py).
-__device__ __forceinline__ bool surface_in_bounds(const RttSurface& S, V3 h) {
-  switch (S.bound_kind) {
+template <class C, class T>
+DI typename LaneOf<T>::M surface_in_bounds(const RttSurface& S, V3<T> h) {
+  switch (C::bk(S)) {
     case RTT_BND_DISK:  // bounded.py:60-64
-      return (h.x * h.x + h.y * h.y) <= S.bnd[0];
+      return le(h.x * h.x + h.y * h.y, splat<T>(S.bnd[0]));
     case RTT_BND_RECT:  // bounded.py:77-82
-      return (fabsf(h.x) <= S.bnd[0]) && (fabsf(h.y) <= S.bnd[1]);
+      return and_(le(abs_(h.x), splat<T>(S.bnd[0])), le(abs_(h.y), splat<T>(S.bnd[1])));
     case RTT_BND_ELLIPSE: {  // bounded.py:98-106
-      const float dM = h.x * S.bnd[0] - h.y * S.bnd[1];
-      const float dm = h.x * S.bnd[1] + h.y * S.bnd[0];
-      const float a = dM / S.bnd[2], b = dm / S.bnd[3];
-      return (a * a + b * b) <= 1.0f;
+      const T dM = h.x * S.bnd[0] - h.y * S.bnd[1];
+      const T dm = h.x * S.bnd[1] + h.y * S.bnd[0];
+      const T a = quot(dM, splat<T>(S.bnd[2]));
+      const T b = quot(dm, splat<T>(S.bnd[3]));
+      return le(a * a + b * b, splat<T>(1.0f));
     }
     case RTT_BND_HALF:  // bounded.py:123-127, :171-174
-      return fabsf(h.z * S.geom[0]) < 1.000001f;
+      return lt(abs_(h.z * S.geom[0]), splat<T>(1.000001f));
     case RTT_BND_HALF_DISK:  // bounded.py:151-159
-      return (fabsf(h.z * S.geom[0]) < 1.000001f) && ((h.x * h.x + h.y * h.y) <= S.bnd[0]);
+      return and_(lt(abs_(h.z * S.geom[0]), splat<T>(1.000001f)), le(h.x * h.x + h.y * h.y, splat<T>(S.bnd[0])));
     case RTT_BND_SINGLE_CONE:  // bounded.py:208-217
-      return (h.z * S.geom[0]) >= -kEps;
+      return ge(h.z * S.geom[0], splat<T>(-kEps));
     default:  // RTT_BND_ALWAYS
-      return true;
+      return ge(splat<T>(1.0f), splat<T>(0.0f));
   }
 }
 
 // Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36)
-__device__ __forceinline__ float filter_root(const RttSurface& S, const Frames& f, float r) {
-  bool bad = r <= kEps;
-  if (S.bound_kind != RTT_BND_NONE) {
-    V3 h = f.pl + r * f.dl;
-    bool keep = surface_in_bounds(S, h);
-    if (S.flags & RTT_F_INVERT) keep = !keep;
-    bad = bad || !keep;
+template <class C, class T>
+DI T filter_root(const RttSurface& S, const Frames<T>& f, T r) {
+  auto bad = le(r, splat<T>(kEps));
+  if (C::bk(S) != RTT_BND_NONE) {
+    V3<T> h = f.pl + scale(r, f.dl);
+    auto keep = surface_in_bounds<C>(S, h);
+    if (S.flags & RTT_F_INVERT) keep = not_(keep);
+    bad = or_(bad, not_(keep));
   }
-  return bad ? kInf : r;
+  return sel(bad, splat<T>(kInf), r);
 }
 
-__device__ __forceinline__ float solve_t(const RttSurface& S, const Frames& f) {
-  float t1, t2;
-  const int n = solve_roots(S, f.pl, f.dl, t1, t2);
-  t1 = filter_root(S, f, t1);
+template <class C, class T>
+DI T solve_t(const RttSurface& S, const Frames<T>& f) {
+  T t1, t2;
+  const int n = solve_roots<C>(S, f.pl, f.dl, t1, t2);
+  t1 = filter_root<C>(S, f, t1);
   if (n == 1) return t1;
-  t2 = filter_root(S, f, t2);
+  t2 = filter_root<C>(S, f, t2);
   return nanmin(t1, t2);
 }
 
 // HalfCyl.sagittalZ with a per-ray height (geom/bounded.py:176-186)
-__device__ __forceinline__ float sag(float c, float tz, float y) {
-  const float r_sq = y * y;
-  float term = 1.0f - (c * c) * r_sq;
-  term = term > 0.0f ? term : (term != term ? term : 0.0f);  // relu keeps NaN
-  return (c * r_sq) / (1.0f + sqrtf(term)) + tz;
+template <class T>
+DI T sag(float c, float tz, T y) {
+  const T r_sq = y * y;
+  T term = 1.0f - (c * c) * r_sq;
+  term = sel(gt(term, splat<T>(0.0f)), term, sel(isnan_(term), term, splat<T>(0.0f)));  // relu keeps NaN
+  const T den = 1.0f + sqrt_(term);
+  return quot(c * r_sq, den) + tz;
 }
 
 // Shape.inBounds(hit, j) in the element frame (geom/spherics.py:27-46, geom/cylindrics.py:23-55)
-__device__ __forceinline__ bool shape_in_bounds(const RttSurface& S, V3 h) {
-  switch (S.shape_kind) {
+template <class C, class T>
+DI typename LaneOf<T>::M shape_in_bounds(const RttSurface& S, V3<T> h) {
+  switch (C::hk(S)) {
     case RTT_SHP_SPHERIC_FACE:
-      return (h.x * h.x + h.y * h.y) <= S.shp[0];
+      return le(h.x * h.x + h.y * h.y, splat<T>(S.shp[0]));
     case RTT_SHP_SPHERIC_EDGE:
-      return (h.z >= S.shp[0]) && (h.z <= S.shp[1]);
+      return and_(ge(h.z, splat<T>(S.shp[0])), le(h.z, splat<T>(S.shp[1])));
     case RTT_SHP_CYL_FACE:
     case RTT_SHP_CYL_EDGE: {
-      const bool ap = (h.x <= S.shp[0]) && (h.x >= S.shp[1]) && (h.y <= S.shp[2]) && (h.y >= S.shp[3]);
-      if (S.shape_kind == RTT_SHP_CYL_FACE) return ap;
-      const float zf = sag(S.shp[4], S.shp[5], h.y);
-      const float zb = sag(S.shp[6], S.shp[7], h.y);
-      return (h.z >= zf + 1e-4f) && (h.z <= zb - 1e-4f) && ap;
+      const auto ap = and_(and_(le(h.x, splat<T>(S.shp[0])), ge(h.x, splat<T>(S.shp[1]))),
+                           and_(le(h.y, splat<T>(S.shp[2])), ge(h.y, splat<T>(S.shp[3]))));
+      if (C::hk(S) == RTT_SHP_CYL_FACE) return ap;
+      const T zf = sag(S.shp[4], S.shp[5], h.y);
+      const T zb = sag(S.shp[6], S.shp[7], h.y);
+      return and_(and_(ge(h.z, zf + 1e-4f), le(h.z, zb - 1e-4f)), ap);
     }
     default:
-      return true;
+      return ge(splat<T>(1.0f), splat<T>(0.0f));
   }
 }
 
 // One column of Element.intersectTest (geom/shape.py:42-56 or geom/primitives.py:38-57).
 // `f` and the un-masked t (what Shape.forward recomputes, geom/shape.py:78) are returned as well.
-__device__ __forceinline__ float test_surface(const RttSurface& S, V3 p, V3 d, Frames& f, float& t_raw) {
-  f = to_frames(S, p, d);
-  float t = solve_t(S, f);
+template <class C, class T>
+DI T test_surface(const RttSurface& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
+  f = to_frames<C>(S, p, d);
+  T t = solve_t<C>(S, f);
   t_raw = t;
-  if (S.flags & RTT_F_HAS_SHAPE) {
-    V3 he = f.pe + t * f.de;
-    const bool valid = (t < kInf) && shape_in_bounds(S, he);
-    t = valid ? t : kInf;
+  if (C::has_shape(S)) {
+    V3<T> he = f.pe + scale(t, f.de);
+    const auto valid = and_(lt(t, splat<T>(kInf)), shape_in_bounds<C>(S, he));
+    t = sel(valid, t, splat<T>(kInf));
   }
   return t;
 }
 
 // _getNormal in the surface frame
-__device__ __forceinline__ V3 surface_normal(const RttSurface& S, V3 h) {
-  switch (S.surf_kind) {
+template <class C, class T>
+DI V3<T> surface_normal(const RttSurface& S, V3<T> h) {
+  const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
+  switch (C::sk(S)) {
     case RTT_SURF_PLANE:  // primitives.py:138-143
-      return {0.0f, 0.0f, 1.0f};
-    case RTT_SURF_SPHERE:  // primitives.py:183-187
-      return {h.x / S.geom[0], h.y / S.geom[0], h.z / S.geom[0]};
-    case RTT_SURF_CYLINDER:  // primitives.py:233-241
-      return {h.x / S.geom[0], h.y / S.geom[0], 0.0f};
+      return {zero, zero, one};
+    case RTT_SURF_SPHERE: {  // primitives.py:183-187
+      const T R = splat<T>(S.geom[0]);
+      return {quot(h.x, R), quot(h.y, R), quot(h.z, R)};
+    }
+    case RTT_SURF_CYLINDER: {  // primitives.py:233-241
+      const T R = splat<T>(S.geom[0]);
+      return {quot(h.x, R), quot(h.y, R), zero};
+    }
     case RTT_SURF_QUADRIC:
     case RTT_SURF_QUADRIC_ZY: {  // primitives.py:330-343, :379-395
       const float two_c = 2.0f * S.geom[0], two_c1k = 2.0f * S.geom[2];
-      const float nx = S.surf_kind == RTT_SURF_QUADRIC ? two_c * h.x : 0.0f;
-      const float ny = two_c * h.y;
-      const float nz = two_c1k * h.z - 2.0f;
-      const float len = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-8f;
-      return {-(nx / len), -(ny / len), -(nz / len)};
+      const T nx = C::sk(S) == RTT_SURF_QUADRIC ? two_c * h.x : zero;
+      const T ny = two_c * h.y;
+      const T nz = two_c1k * h.z - 2.0f;
+      const T len = sqrt_(nx * nx + ny * ny + nz * nz) + 1e-8f;
+      if (kStrict) return {-div_ieee(nx, len), -div_ieee(ny, len), -div_ieee(nz, len)};
+      const T r = -rcp_(len);
+      return {nx * r, ny * r, nz * r};
     }
     default: {  // cone, primitives.py:468-497
       const float k2 = S.geom[1];
-      const float nx = -k2 * h.x, ny = -k2 * h.y, nz = h.z;
-      const float len = sqrtf(nx * nx + ny * ny + nz * nz);
-      if (len > 1e-8f) {
-        const float l = len + 1e-8f;
-        return {nx / l, ny / l, nz / l};
-      }
-      return {0.0f, 0.0f, 1.0f};
+      const T nx = -k2 * h.x, ny = -k2 * h.y, nz = h.z;
+      const T len = sqrt_(nx * nx + ny * ny + nz * nz);
+      const auto ok = gt(len, splat<T>(1e-8f));
+      const T l = len + 1e-8f;
+      return {sel(ok, quot(nx, l), zero), sel(ok, quot(ny, l), zero), sel(ok, quot(nz, l), one)};
     }
   }
 }
 
+template <class T>
 struct Forward {
-  V3 hit_g, hit_l, n_g;
+  V3<T> hit_g, hit_l, n_g;
 };
 
 // Shape.forward / Surface.forward given frames and t (geom/shape.py:78-87, geom/primitives.py:85-96)
-__device__ __forceinline__ Forward surface_forward(const RttSurface& S, V3 p, V3 d, const Frames& f, float t) {
-  Forward o;
-  o.hit_g = p + t * d;
-  o.hit_l = f.pl + t * f.dl;
-  V3 n = surface_normal(S, o.hit_l);
-  n = rowmat_t(n, S.Rj, S.flags & RTT_F_SURF_ROT_ID);
-  if (S.flags & RTT_F_HAS_SHAPE) n = rowmat_t(n, S.Rs, S.flags & RTT_F_SHAPE_ROT_ID);
+template <class C, class T>
+DI Forward<T> surface_forward(const RttSurface& S, V3<T> p, V3<T> d, const Frames<T>& f, T t) {
+  Forward<T> o;
+  o.hit_g = p + scale(t, d);
+  o.hit_l = f.pl + scale(t, f.dl);
+  V3<T> n = surface_normal<C>(S, o.hit_l);
+  n = rowmat_t(n, S.Rj, C::rj_id(S));
+  if (C::has_shape(S)) n = rowmat_t(n, S.Rs, C::rs_id(S));
   o.n_g = n;
   return o;
 }
 
 // SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult)
-__device__ __forceinline__ void apply_physics(const RttSurface& S, V3 hl, V3 d, V3 n, V3& nd, float& im) {
-  switch (S.phys_kind) {
+template <class C, class T>
+DI void apply_physics(const RttSurface& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im) {
+  const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
+  switch (C::pk(S)) {
     case RTT_PHYS_BLOCK:  // phys/std.py:243-254
-      nd = {0.0f, 0.0f, 0.0f};
-      im = 0.0f;
+      nd = {zero, zero, zero};
+      im = zero;
       return;
     case RTT_PHYS_REFLECT: {  // phys/std.py:97-108
-      const float two_cos = 2.0f * dot3(d, n);
-      nd = d - two_cos * n;
-      im = 1.0f;
+      const T two_cos = 2.0f * dot3(d, n);
+      nd = d - scale(two_cos, n);
+      im = one;
       return;
     }
     case RTT_PHYS_SNELL: {  // phys/std.py:123-145
-      const float dot = dot3(d, n);
-      const bool ent = dot < 0.0f;
-      const V3 ne = ent ? n : V3{-n.x, -n.y, -n.z};
-      const float c1 = fabsf(dot);
-      const float mu = ent ? S.phys[2] : S.phys[3];
-      const float term = 1.0f - mu * mu * (1.0f - c1 * c1);
-      if (term < 0.0f) {
-        const float two_dot = 2.0f * dot;
-        nd = d - two_dot * n;
-      } else {
-        const float c2 = sqrtf(term > 0.0f ? term : (term != term ? term : 0.0f));
-        const float g = mu * c1 - c2;
-        nd = mu * d + g * ne;
+      const T dot = dot3(d, n);
+      const auto ent = lt(dot, zero);
+      const V3<T> ne = {sel(ent, n.x, -n.x), sel(ent, n.y, -n.y), sel(ent, n.z, -n.z)};
+      const T c1 = abs_(dot);
+      const T mu = sel(ent, splat<T>(S.phys[2]), splat<T>(S.phys[3]));
+      const T term = 1.0f - mu * mu * (1.0f - c1 * c1);
+      const T c2 = sqrt_(sel(gt(term, zero), term, sel(isnan_(term), term, zero)));  // sqrt(relu(term))
+      const T g = mu * c1 - c2;
+      const V3<T> refr = scale(mu, d) + scale(g, ne);
+      const auto tir = lt(term, zero);
+      nd = refr;
+      if (any_(tir)) {
+        const T two_dot = 2.0f * dot;
+        nd = sel3(tir, d - scale(two_dot, n), refr);
       }
-      im = 1.0f;
+      im = one;
       return;
     }
     case RTT_PHYS_APERTURE: {  // phys/filter.py:24-33
-      const float m = surface_in_bounds(S, hl) ? 1.0f : 0.0f;
-      nd = m * d;
+      const T m = sel(surface_in_bounds<C>(S, hl), one, zero);
+      nd = scale(m, d);
       im = m;
       return;
     }
     default:  // RTT_PHYS_TRANSMIT, phys/std.py:227-235
       nd = d;
-      im = 1.0f;
+      im = one;
       return;
   }
 }
@@ -361,67 +543,96 @@ struct SensorIO {
   int64_t ld;
 };
 
-__device__ __forceinline__ void load_ray(const RayIO& io, int64_t i, V3& p, V3& d, float& I) {
-  p = {io.pos_in[i], io.pos_in[io.ld_in + i], io.pos_in[2 * io.ld_in + i]};
-  d = {io.dir_in[i], io.dir_in[io.ld_in + i], io.dir_in[2 * io.ld_in + i]};
-  I = io.inten_in[i];
+template <class T>
+struct Ray {
+  V3<T> p, d;
+  T I;
+};
+
+// lane type T at ray index i: float reads ray i, f2 reads rays i and i+1 with one 8-byte access
+template <class T> DI T ld_(const float* p, int64_t i) { return *reinterpret_cast<const T*>(p + i); }
+template <class T> DI void st_(float* p, int64_t i, T v) { *reinterpret_cast<T*>(p + i) = v; }
+
+template <class T>
+DI Ray<T> load_ray(const RayIO& io, int64_t i) {
+  Ray<T> r;
+  r.p = {ld_<T>(io.pos_in, i), ld_<T>(io.pos_in + io.ld_in, i), ld_<T>(io.pos_in + 2 * io.ld_in, i)};
+  r.d = {ld_<T>(io.dir_in, i), ld_<T>(io.dir_in + io.ld_in, i), ld_<T>(io.dir_in + 2 * io.ld_in, i)};
+  r.I = ld_<T>(io.inten_in, i);
+  return r;
 }
 
-__device__ __forceinline__ void store_ray(const RayIO& io, int64_t i, V3 p, V3 d, float I) {
-  io.pos_out[i] = p.x;
-  io.pos_out[io.ld_out + i] = p.y;
-  io.pos_out[2 * io.ld_out + i] = p.z;
-  io.dir_out[i] = d.x;
-  io.dir_out[io.ld_out + i] = d.y;
-  io.dir_out[2 * io.ld_out + i] = d.z;
-  io.inten_out[i] = I;
+template <class T>
+DI void store_ray(const RayIO& io, int64_t i, const Ray<T>& r) {
+  st_<T>(io.pos_out, i, r.p.x);
+  st_<T>(io.pos_out + io.ld_out, i, r.p.y);
+  st_<T>(io.pos_out + 2 * io.ld_out, i, r.p.z);
+  st_<T>(io.dir_out, i, r.d.x);
+  st_<T>(io.dir_out + io.ld_out, i, r.d.y);
+  st_<T>(io.dir_out + 2 * io.ld_out, i, r.d.z);
+  st_<T>(io.inten_out, i, r.I);
 }
 
-__device__ __forceinline__ void record_sensor(const SensorIO& se, int slot, int64_t i, bool hit, V3 hl, float I) {
+template <class T, class M>
+DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, T I) {
   const int64_t base = (int64_t)slot * se.ld;
-  se.mask[base + i] = hit ? 1 : 0;
-  if (hit) {
-    se.hit[(3 * base) + i] = hl.x;
-    se.hit[(3 * base) + se.ld + i] = hl.y;
-    se.hit[(3 * base) + 2 * se.ld + i] = hl.z;
-    se.w[base + i] = I;
+#pragma unroll
+  for (int k = 0; k < LaneOf<T>::N; ++k) {
+    const bool h = mcomp(hit, k);
+    se.mask[base + i + k] = h ? 1 : 0;
+    if (h) {
+      se.hit[(3 * base) + i + k] = comp(hl.x, k);
+      se.hit[(3 * base) + se.ld + i + k] = comp(hl.y, k);
+      se.hit[(3 * base) + 2 * se.ld + i + k] = comp(hl.z, k);
+      se.w[base + i + k] = comp(I, k);
+    }
   }
 }
 
-// Apply surface S to one ray if it is hit: Element.forward + Rays.scatter_update
+// Apply surface S to the ray(s) of a lane where hit: Element.forward + Rays.scatter_update
 // (elements/parent.py:44-58, rays/ray.py:29-40, elements/sensor.py:35-37).
-__device__ __forceinline__ void interact(const RttSurface& S, const Frames& f, float t_raw, bool hit, V3& p, V3& d,
-                                         float& I, const SensorIO& se, int64_t i) {
-  Forward fw = surface_forward(S, p, d, f, t_raw);
-  V3 nd;
-  float im;
-  apply_physics(S, fw.hit_l, d, fw.n_g, nd, im);
-  if (S.flags & RTT_F_SENSOR) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, I);
-  if (hit) {
-    p = fw.hit_g;
-    d = nd;
-    I = I * im;
-  }
+template <class C, class T, class M>
+DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i) {
+  Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
+  V3<T> nd;
+  T im;
+  apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im);
+  if (S.flags & RTT_F_SENSOR) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, r.I);
+  r.p = sel3(hit, fw.hit_g, r.p);
+  r.d = sel3(hit, nd, r.d);
+  r.I = sel(hit, r.I * im, r.I);
+}
+
+// test + interact of one surface (scene/sequential.py:19-34)
+template <class C, class T>
+DI void visit_seq(const RttSurface& S, Ray<T>& r, const SensorIO& se, int64_t i) {
+  Frames<T> f;
+  T t_raw;
+  const T t = test_surface<C>(S, r.p, r.d, f, t_raw);
+  interact<C>(S, f, t_raw, lt(t, splat<T>(kInf)), r, se, i);
 }
 
 // ------------------------------------------------------------------------------------------------
 // SequentialScene.simulate (scene/sequential.py:12-36)
+// T = f2: lane l of a block works on the adjacent rays (2l, 2l+1) of its tile, read and written
+// with 8-byte accesses (512 contiguous bytes per wavefront instruction); the host launches this
+// form on the even-length, 8-byte aligned part of the bundle and T = float on what is left.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
-                                                      SensorIO se) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
-    V3 p, d;
-    float I;
-    load_ray(io, i, p, d, I);
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                      Ops ops, SensorIO se) {
+  constexpr int N = LaneOf<T>::N;
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
+  const int64_t stride = (int64_t)gridDim.x * kBlock * N;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < io.n; i += stride) {
+    Ray<T> r = load_ray<T>(io, i);
     for (int s = 0; s < n_surf; ++s) {
       const RttSurface& S = prog[s];
-      Frames f;
-      float t_raw;
-      const float t = test_surface(S, p, d, f, t_raw);
-      interact(S, f, t_raw, t < kInf, p, d, I, se, i);
+#define RTT_CALL(CFG) visit_seq<CFG>(S, r, se, i)
+      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+#undef RTT_CALL
     }
-    store_ray(io, i, p, d, I);
+    store_ray<T>(io, i, r);
   }
 }
 
@@ -429,14 +640,17 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
 // Scene.ray_cast / Scene.step (scene/base.py:144-235)
 // ------------------------------------------------------------------------------------------------
 // torch.min(t_matrix, dim=1): first index of the smallest value, NaN wins and sticks.
-__device__ __forceinline__ void nearest(const RttSurface* __restrict__ prog, int n_surf, V3 p, V3 d, float& tmin,
-                                        int& win) {
+DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<float> p, V3<float> d,
+                float& tmin, int& win) {
   tmin = kInf;
   win = 0;
   for (int s = 0; s < n_surf; ++s) {
-    Frames f;
-    float t_raw;
-    const float t = test_surface(prog[s], p, d, f, t_raw);
+    const RttSurface& S = prog[s];
+    Frames<float> f;
+    float t_raw, t;
+#define RTT_CALL(CFG) t = test_surface<CFG>(S, p, d, f, t_raw)
+    RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+#undef RTT_CALL
     const bool take = (tmin == tmin) && ((t != t) || (t < tmin));
     if (take) {
       tmin = t;
@@ -447,47 +661,52 @@ __device__ __forceinline__ void nearest(const RttSurface* __restrict__ prog, int
 }
 
 __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ pos, const float* __restrict__ dir,
-                                                     int64_t ld, int64_t n, const RttSurface* __restrict__ prog,
-                                                     int n_surf, int32_t* __restrict__ winner,
+                                                     int64_t ld, int64_t n, const RttSurface* __restrict__ prog_,
+                                                     int n_surf, Ops ops, int32_t* __restrict__ winner,
                                                      float* __restrict__ tmin_out) {
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    V3 p = {pos[i], pos[ld + i], pos[2 * ld + i]};
-    V3 d = {dir[i], dir[ld + i], dir[2 * ld + i]};
+    V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
+    V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
     float tmin;
     int win;
-    nearest(prog, n_surf, p, d, tmin, win);
+    nearest(prog, n_surf, ops, p, d, tmin, win);
     if (winner) winner[i] = win;
     if (tmin_out) tmin_out[i] = tmin;
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
-                                                         int32_t* __restrict__ winner, SensorIO se) {
+__global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                         Ops ops, int32_t* __restrict__ winner, SensorIO se) {
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
-    V3 p, d;
-    float I;
-    load_ray(io, i, p, d, I);
+    Ray<float> r = load_ray<float>(io, i);
     float tmin;
     int win;
-    nearest(prog, n_surf, p, d, tmin, win);
+    nearest(prog, n_surf, ops, r.p, r.d, tmin, win);
     if (winner) winner[i] = win;
     // active_mask = hit & (intensity > 0), scene/base.py:201
-    bool pending = (win >= 0) && (I > 0.0f);
+    bool pending = (win >= 0) && (r.I > 0.0f);
     // Lanes of one wavefront may have won different surfaces: serve one surface per pass with its
     // record held in scalar registers (readfirstlane picks the surface of the first pending lane).
     while (pending) {
       const int s = __builtin_amdgcn_readfirstlane(win);
       if (win == s) {
         const RttSurface& S = prog[s];
-        Frames f = to_frames(S, p, d);
-        const float t_raw = solve_t(S, f);
-        interact(S, f, t_raw, true, p, d, I, se, i);
+#define RTT_CALL(CFG)                                  \
+  {                                                    \
+    Frames<float> f = to_frames<CFG>(S, r.p, r.d);     \
+    const float t_raw = solve_t<CFG>(S, f);            \
+    interact<CFG>(S, f, t_raw, true, r, se, i);        \
+  }
+        RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+#undef RTT_CALL
         pending = false;
       }
     }
-    store_ray(io, i, p, d, I);
+    store_ray<float>(io, i, r);
   }
 }
 
@@ -500,12 +719,12 @@ __global__ void __launch_bounds__(kBlock) k_intersect_test(const float* __restri
                                                            float* __restrict__ t_out, int64_t ld_t) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    V3 p = {pos[i], pos[ld + i], pos[2 * ld + i]};
-    V3 d = {dir[i], dir[ld + i], dir[2 * ld + i]};
+    V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
+    V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
     for (int s = 0; s < n_surf; ++s) {
-      Frames f;
+      Frames<float> f;
       float t_raw;
-      t_out[(int64_t)s * ld_t + i] = test_surface(prog[s], p, d, f, t_raw);
+      t_out[(int64_t)s * ld_t + i] = test_surface<CGeneric>(prog[s], p, d, f, t_raw);
     }
   }
 }
@@ -523,7 +742,7 @@ struct ForwardOut {
   int64_t ld;
 };
 
-__device__ __forceinline__ void store3(float* base, int64_t ld, int64_t i, V3 v) {
+__device__ __forceinline__ void store3(float* base, int64_t ld, int64_t i, V3<float> v) {
   if (base) {
     base[i] = v.x;
     base[ld + i] = v.y;
@@ -538,19 +757,19 @@ __global__ void __launch_bounds__(kBlock) k_surface_forward(const float* __restr
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const RttSurface& S = prog[index];
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    V3 p = {pos[i], pos[ld + i], pos[2 * ld + i]};
-    V3 d = {dir[i], dir[ld + i], dir[2 * ld + i]};
-    Frames f = to_frames(S, p, d);
-    const float t = solve_t(S, f);
-    Forward fw = surface_forward(S, p, d, f, t);
+    V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
+    V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
+    Frames<float> f = to_frames<CGeneric>(S, p, d);
+    const float t = solve_t<CGeneric>(S, f);
+    Forward<float> fw = surface_forward<CGeneric>(S, p, d, f, t);
     if (o.t) o.t[i] = t;
     store3(o.hit_g, o.ld, i, fw.hit_g);
     store3(o.n_g, o.ld, i, fw.n_g);
     store3(o.hit_l, o.ld, i, fw.hit_l);
     if (o.new_dir || o.imult) {
-      V3 nd;
+      V3<float> nd;
       float im;
-      apply_physics(S, fw.hit_l, d, fw.n_g, nd, im);
+      apply_physics<CGeneric>(S, fw.hit_l, d, fw.n_g, nd, im);
       store3(o.new_dir, o.ld, i, nd);
       if (o.imult) o.imult[i] = im;
     }
@@ -564,12 +783,12 @@ __global__ void __launch_bounds__(kBlock) k_apply_physics(const float* __restric
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const RttSurface& S = prog[0];
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    V3 h = {hl[i], hl[ld + i], hl[2 * ld + i]};
-    V3 d = {dir[i], dir[ld + i], dir[2 * ld + i]};
-    V3 nn = {nrm[i], nrm[ld + i], nrm[2 * ld + i]};
-    V3 nd;
+    V3<float> h = {hl[i], hl[ld + i], hl[2 * ld + i]};
+    V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
+    V3<float> nn = {nrm[i], nrm[ld + i], nrm[2 * ld + i]};
+    V3<float> nd;
     float im;
-    apply_physics(S, h, d, nn, nd, im);
+    apply_physics<CGeneric>(S, h, d, nn, nd, im);
     store3(new_dir, ld, i, nd);
     imult[i] = im;
   }
@@ -636,12 +855,48 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int grid_for(int64_t n) {
-  // memory-bound streaming: cap the grid at 256 CUs x 8 resident blocks and grid-stride the rest
-  int64_t blocks = (n + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
+// tuning knobs (rtt_tune): rays carried per lane in the sequential trace, and the grid cap
+int g_rays_per_lane = 2;
+// One tile per block by default: blocks that finish are replaced by blocks that start with their
+// loads, which overlaps HBM latency with the arithmetic of the resident waves (measured on the 64 Mi
+// singlet trace: 0.83 ms with a 2048-block grid-stride cap, 0.77 ms uncapped).
+int g_max_blocks = 1 << 20;
+
+int grid_for(int64_t n, int rays_per_lane = 1) {
+  const int64_t tile = (int64_t)kBlock * rays_per_lane;
+  int64_t blocks = (n + tile - 1) / tile;
+  if (blocks > g_max_blocks) blocks = g_max_blocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
+}
+
+// Pick the visit configuration of one record: a specialised one only when every kind and flag it
+// fixes at compile time matches; anything else runs the generic interpreter.
+int classify(const RttSurface& S) {
+  const int all_id = RTT_F_SHAPE_ROT_ID | RTT_F_SURF_ROT_ID;
+  const bool ident = (S.flags & all_id) == all_id;
+  const bool shaped = (S.flags & RTT_F_HAS_SHAPE) != 0;
+  auto is = [&](int sk, int bk, int hk) { return S.surf_kind == sk && S.bound_kind == bk && S.shape_kind == hk; };
+  if (shaped && ident && is(RTT_SURF_QUADRIC, RTT_BND_HALF, RTT_SHP_SPHERIC_FACE) && S.phys_kind == RTT_PHYS_SNELL)
+    return OP_FACE_SNELL;
+  if (shaped && ident && is(RTT_SURF_CYLINDER, RTT_BND_NONE, RTT_SHP_SPHERIC_EDGE)) {
+    if (S.phys_kind == RTT_PHYS_BLOCK) return OP_EDGE_BLOCK;
+    if (S.phys_kind == RTT_PHYS_SNELL) return OP_EDGE_SNELL;
+  }
+  if (!shaped && ident && is(RTT_SURF_PLANE, RTT_BND_DISK, RTT_SHP_NONE)) return OP_DISK_PLANE;
+  if (!shaped && ident && is(RTT_SURF_QUADRIC, RTT_BND_HALF_DISK, RTT_SHP_NONE) && S.phys_kind == RTT_PHYS_REFLECT)
+    return OP_MIRROR_CAP;
+  if (shaped && ident && is(RTT_SURF_QUADRIC_ZY, RTT_BND_HALF, RTT_SHP_CYL_FACE) && S.phys_kind == RTT_PHYS_SNELL)
+    return OP_CYL_FACE_SNELL;
+  if (shaped && is(RTT_SURF_PLANE, RTT_BND_NONE, RTT_SHP_CYL_EDGE)) return OP_CYL_SIDE;
+  return OP_GENERIC;
+}
+
+Ops make_ops(const RttSurface* host, int n_surf) {
+  Ops ops = {};
+  if (host)
+    for (int s = 0; s < n_surf; ++s) ops.w[s >> 2] |= (uint32_t)classify(host[s]) << ((s & 3) * 8);
+  return ops;
 }
 
 int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_slots) {
@@ -691,8 +946,31 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
-  hipLaunchKernelGGL(k_trace_seq, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev, n_surf,
-                     se);
+  const Ops ops = make_ops(prog_host, n_surf);
+  const hipStream_t st = (hipStream_t)stream;
+  // Packed form (two adjacent rays per lane, 8-byte accesses) on the even-length part when every plane
+  // is 8-byte aligned; one ray per lane on the remainder or on everything otherwise.
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const bool can_pack = g_rays_per_lane >= 2 && (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) &&
+                        aligned8(dir_in) && aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) &&
+                        aligned8(inten_out);
+  const int64_t n_pack = can_pack ? (n & ~(int64_t)1) : 0;
+  if (n_pack > 0) {
+    RayIO io2 = io;
+    io2.n = n_pack;
+    hipLaunchKernelGGL(k_trace_seq<f2>, dim3(grid_for(n_pack, 2)), dim3(kBlock), 0, st, io2, prog_dev, n_surf, ops,
+                       se);
+  }
+  if (n_pack < n) {
+    RayIO io1 = io;
+    io1.pos_in += n_pack; io1.dir_in += n_pack; io1.inten_in += n_pack;
+    io1.pos_out += n_pack; io1.dir_out += n_pack; io1.inten_out += n_pack;
+    io1.n = n - n_pack;
+    SensorIO se1 = se;
+    if (se1.hit) { se1.hit += n_pack; se1.w += n_pack; se1.mask += n_pack; }
+    hipLaunchKernelGGL(k_trace_seq<float>, dim3(grid_for(n - n_pack, 1)), dim3(kBlock), 0, st, io1, prog_dev, n_surf,
+                       ops, se1);
+  }
   return launch_status();
 }
 
@@ -705,7 +983,7 @@ int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, 
   if (rc != RTT_OK) return rc;
   if (n == 0) return RTT_OK;
   hipLaunchKernelGGL(k_ray_cast, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, pos, dir, ld, n,
-                     prog_dev, n_surf, winner, tmin);
+                     prog_dev, n_surf, make_ops(prog_host, n_surf), winner, tmin);
   return launch_status();
 }
 
@@ -729,7 +1007,7 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
   hipLaunchKernelGGL(k_step_nearest, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
-                     n_surf, winner, se);
+                     n_surf, make_ops(prog_host, n_surf), winner, se);
   return launch_status();
 }
 
@@ -805,6 +1083,18 @@ const char* rtt_strerror(int code) {
 }
 
 int rtt_abi_version(void) { return RTT_ABI_VERSION; }
+
+int rtt_tune(int key, int value) {
+  if (key == 0 && (value == 1 || value == 2)) {
+    g_rays_per_lane = value;
+    return RTT_OK;
+  }
+  if (key == 1 && value >= 1 && value <= (1 << 20)) {
+    g_max_blocks = value;
+    return RTT_OK;
+  }
+  return RTT_E_SIZE;
+}
 
 int rtt_surface_record_bytes(void) { return (int)sizeof(RttSurface); }
 
