@@ -90,6 +90,16 @@ DI float sqrt_(float x) { return kStrict ? sqrtf(x) : __builtin_amdgcn_sqrtf(x);
 DI f2 sqrt_(f2 x) { return f2{sqrt_(x.x), sqrt_(x.y)}; }
 DI float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
 DI f2 rsq_(f2 x) { return f2{rsq_(x.x), rsq_(x.y)}; }
+// sqrt for the discriminant: hardware sqrt (<= 1 ulp) plus one Newton step on the exact residual
+// fma(-s, s, x); the result is within 0.5 ulp (+ 2^-24 relative) of the true root, i.e. correctly
+// rounded except for rare near-ties, at a third of the instructions of the full IEEE expansion.
+DI float sqrt_disc(float x) {
+  if (kStrict) return sqrtf(x);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float h = 0.5f * __builtin_amdgcn_rsqf(fmaxf(x, 1e-37f));
+  return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+}
+DI f2 sqrt_disc(f2 x) { return f2{sqrt_disc(x.x), sqrt_disc(x.y)}; }
 DI float quot(float a, float b) { return kStrict ? a / b : a * rcp_(b); }
 DI f2 quot(f2 a, f2 b) { return kStrict ? a / b : a * rcp_(b); }
 template <class T> DI T splat(float v) { return T(v); }
@@ -234,54 +244,58 @@ DI Frames<T> to_frames(const RttSurface& S, V3<T> p, V3<T> d) {
 }
 
 // Quadric._solve_quadratic (geom/primitives.py:290-320) and the Cone variant (:436-466).
-template <bool ABS_DISC, class T>
-DI void quadratic_with_linear_fallback(T A, T B, T Cc, T& t1, T& t2) {
-  const T inf = splat<T>(kInf), eps = splat<T>(kEps);
+// Roots come back with a validity mask instead of being overwritten with inf: `ok` false means the
+// reference's value is inf (complex roots), which the root filter turns into a miss either way.
+template <bool ABS_DISC, class T, class M>
+DI void quadratic_with_linear_fallback(T A, T B, T Cc, T& t1, T& t2, M& ok) {
+  const T eps = splat<T>(kEps);
   const T disc = B * B - 4.0f * A * Cc;
   const auto hit = ge(disc, splat<T>(0.0f));
   const auto lin = lt(abs_(A), eps);
-  // correctly rounded in both builds: the root -B - sqrt(disc) cancels for near-paraxial rays and
-  // amplifies every ulp of the square root
-  const T sq = ABS_DISC ? sqrt_ieee(abs_(disc)) : sqrt_ieee(sel(hit, disc, splat<T>(0.0f)));
-  const T A_safe = sel(lin, splat<T>(1.0f), A);
-  const T den = 2.0f * A_safe;
+  // kept (nearly) correctly rounded in both builds: the root -B - sqrt(disc) cancels for near-paraxial
+  // rays and amplifies every ulp of the square root
+  const T sq = ABS_DISC ? sqrt_disc(abs_(disc)) : sqrt_disc(sel(hit, disc, splat<T>(0.0f)));
   if (kStrict) {
+    const T den = 2.0f * sel(lin, splat<T>(1.0f), A);
     t1 = div_ieee(-B - sq, den);
     t2 = div_ieee(-B + sq, den);
   } else {
-    const T r = rcp_(den);
+    // |A| < eps lanes take the linear root below, so the guard A_safe = 1 of the reference is not needed
+    const T r = rcp_(2.0f * A);
     t1 = (-B - sq) * r;
     t2 = (-B + sq) * r;
   }
-  t1 = sel(hit, t1, inf);
-  t2 = sel(hit, t2, inf);
+  ok = hit;
   if (any_(lin)) {
     const T B_safe = sel(lt(abs_(B), eps), eps, B);
     const T tl = quot(-Cc, B_safe);
     t1 = sel(lin, tl, t1);
     t2 = sel(lin, tl, t2);
+    ok = or_(hit, lin);
   }
 }
 
-// _solve_t of each primitive in the surface frame.  Returns the number of roots (1 or 2).
-template <class C, class T>
-DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2) {
-  const T inf = splat<T>(kInf), zero = splat<T>(0.0f);
+// _solve_t of each primitive in the surface frame.  Returns the number of roots (1 or 2); `ok`
+// false marks roots the reference sets to inf.
+template <class C, class T, class M>
+DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
+  const T zero = splat<T>(0.0f);
   switch (C::sk(S)) {
     case RTT_SURF_PLANE: {  // geom/primitives.py:124-136
       const T safe = sel(lt(abs_(d.z), splat<T>(kEps)), splat<T>(1e-8f), d.z);
       t1 = quot(-o.z, safe);
       t2 = t1;
+      ok = ge(splat<T>(1.0f), zero);
       return 1;
     }
     case RTT_SURF_SPHERE: {  // geom/primitives.py:155-181
       const T b = 2.0f * dot3(o, d);
       const T c = dot3(o, o) - S.geom[1];
       const T disc = b * b - 4.0f * c;
-      const auto hit = ge(disc, zero);
-      const T sq = sqrt_ieee(sel(hit, disc, zero));
-      t1 = sel(hit, (-b - sq) * 0.5f, inf);
-      t2 = sel(hit, (-b + sq) * 0.5f, inf);
+      ok = ge(disc, zero);
+      const T sq = sqrt_disc(sel(ok, disc, zero));
+      t1 = (-b - sq) * 0.5f;
+      t2 = (-b + sq) * 0.5f;
       return 2;
     }
     case RTT_SURF_CYLINDER: {  // geom/primitives.py:201-231
@@ -289,12 +303,12 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2) {
       const T B = 2.0f * (o.x * d.x + o.y * d.y);
       const T Cc = (o.x * o.x + o.y * o.y) - S.geom[1];
       const T disc = B * B - 4.0f * A * Cc;
-      const auto hit = ge(disc, zero);
-      const T sq = sqrt_ieee(abs_(disc));
+      ok = ge(disc, zero);
+      const T sq = sqrt_disc(abs_(disc));
       const T den = 2.0f * A;
       // A == 0 gives 1/den = inf; (-B -+ sq) * inf is inf or NaN exactly as the quotient by zero is
-      t1 = sel(hit, quot(-B - sq, den), inf);
-      t2 = sel(hit, quot(-B + sq, den), inf);
+      t1 = quot(-B - sq, den);
+      t2 = quot(-B + sq, den);
       return 2;
     }
     case RTT_SURF_QUADRIC: {  // geom/primitives.py:266-288
@@ -303,7 +317,7 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2) {
       const T A = c * (d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
       const T B = two_c * (o.x * d.x + o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
       const T Cc = c * (o.x * o.x + o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
-      quadratic_with_linear_fallback<true>(A, B, Cc, t1, t2);
+      quadratic_with_linear_fallback<true>(A, B, Cc, t1, t2, ok);
       return 2;
     }
     case RTT_SURF_QUADRIC_ZY: {  // geom/primitives.py:356-377
@@ -312,7 +326,7 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2) {
       const T A = c * (d.y * d.y) + c1k * (d.z * d.z);
       const T B = two_c * (o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
       const T Cc = c * (o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
-      quadratic_with_linear_fallback<true>(A, B, Cc, t1, t2);
+      quadratic_with_linear_fallback<true>(A, B, Cc, t1, t2, ok);
       return 2;
     }
     default: {  // RTT_SURF_CONE, geom/primitives.py:416-466
@@ -320,7 +334,7 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2) {
       const T A = d.z * d.z - k2 * (d.x * d.x + d.y * d.y);
       const T B = 2.0f * (o.z * d.z - k2 * (o.x * d.x + o.y * d.y));
       const T Cc = o.z * o.z - k2 * (o.x * o.x + o.y * o.y);
-      quadratic_with_linear_fallback<false>(A, B, Cc, t1, t2);
+      quadratic_with_linear_fallback<false>(A, B, Cc, t1, t2, ok);
       return 2;
     }
   }
@@ -352,10 +366,12 @@ DI typename LaneOf<T>::M surface_in_bounds(const RttSurface& S, V3<T> h) {
   }
 }
 
-// Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36)
-template <class C, class T>
-DI T filter_root(const RttSurface& S, const Frames<T>& f, T r) {
-  auto bad = le(r, splat<T>(kEps));
+// Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36).
+// `ok` false stands for a root the reference has already replaced by inf: inf fails neither the
+// epsilon test nor (as a NaN hit point) an un-inverted bound, so it stays inf there as here.
+template <class C, class T, class M>
+DI T filter_root(const RttSurface& S, const Frames<T>& f, T r, M ok) {
+  auto bad = or_(not_(ok), le(r, splat<T>(kEps)));
   if (C::bk(S) != RTT_BND_NONE) {
     V3<T> h = f.pl + scale(r, f.dl);
     auto keep = surface_in_bounds<C>(S, h);
@@ -368,10 +384,13 @@ DI T filter_root(const RttSurface& S, const Frames<T>& f, T r) {
 template <class C, class T>
 DI T solve_t(const RttSurface& S, const Frames<T>& f) {
   T t1, t2;
-  const int n = solve_roots<C>(S, f.pl, f.dl, t1, t2);
-  t1 = filter_root<C>(S, f, t1);
+  typename LaneOf<T>::M ok;
+  const int n = solve_roots<C>(S, f.pl, f.dl, t1, t2, ok);
+  t1 = filter_root<C>(S, f, t1, ok);
   if (n == 1) return t1;
-  t2 = filter_root<C>(S, f, t2);
+  t2 = filter_root<C>(S, f, t2, ok);
+  // a NaN root survives only on unbounded surfaces or inverted bounds (a NaN hit point is out of bounds)
+  if (C::bk(S) != RTT_BND_NONE && !(S.flags & RTT_F_INVERT)) return min_(t1, t2);
   return nanmin(t1, t2);
 }
 
@@ -407,19 +426,26 @@ DI typename LaneOf<T>::M shape_in_bounds(const RttSurface& S, V3<T> h) {
   }
 }
 
-// One column of Element.intersectTest (geom/shape.py:42-56 or geom/primitives.py:38-57).
-// `f` and the un-masked t (what Shape.forward recomputes, geom/shape.py:78) are returned as well.
+// One column of Element.intersectTest (geom/shape.py:42-56 or geom/primitives.py:38-57), returned as
+// the hit mask `t < inf` together with the frames and the un-masked t (what Shape.forward recomputes,
+// geom/shape.py:78).  masked_t() gives the column value itself.
 template <class C, class T>
-DI T test_surface(const RttSurface& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
+DI typename LaneOf<T>::M test_surface(const RttSurface& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
   f = to_frames<C>(S, p, d);
-  T t = solve_t<C>(S, f);
-  t_raw = t;
+  t_raw = solve_t<C>(S, f);
+  auto valid = lt(t_raw, splat<T>(kInf));
   if (C::has_shape(S)) {
-    V3<T> he = f.pe + scale(t, f.de);
-    const auto valid = and_(lt(t, splat<T>(kInf)), shape_in_bounds<C>(S, he));
-    t = sel(valid, t, splat<T>(kInf));
+    V3<T> he = f.pe + scale(t_raw, f.de);
+    valid = and_(valid, shape_in_bounds<C>(S, he));
   }
-  return t;
+  return valid;
+}
+
+// the [N, K] matrix entry: a Shape replaces every invalid t (NaN included) by inf, a bare Surface
+// returns its t as is (geom/shape.py:50-55 vs geom/primitives.py:55-57)
+template <class C, class T, class M>
+DI T masked_t(const RttSurface& S, T t_raw, M valid) {
+  return C::has_shape(S) ? sel(valid, t_raw, splat<T>(kInf)) : t_raw;
 }
 
 // _getNormal in the surface frame
@@ -495,13 +521,14 @@ DI void apply_physics(const RttSurface& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd
     case RTT_PHYS_SNELL: {  // phys/std.py:123-145
       const T dot = dot3(d, n);
       const auto ent = lt(dot, zero);
-      const V3<T> ne = {sel(ent, n.x, -n.x), sel(ent, n.y, -n.y), sel(ent, n.z, -n.z)};
       const T c1 = abs_(dot);
       const T mu = sel(ent, splat<T>(S.phys[2]), splat<T>(S.phys[3]));
       const T term = 1.0f - mu * mu * (1.0f - c1 * c1);
-      const T c2 = sqrt_(sel(gt(term, zero), term, sel(isnan_(term), term, zero)));  // sqrt(relu(term))
-      const T g = mu * c1 - c2;
-      const V3<T> refr = scale(mu, d) + scale(g, ne);
+      // sqrt(relu(term)); a NaN term comes with a NaN c1, so the result is NaN through g either way
+      const T c2 = sqrt_(max_(term, zero));
+      // (mu c1 - c2) * (entering ? n : -n), the sign moved onto the scalar factor (exact)
+      const T g = sel(ent, mu * c1 - c2, c2 - mu * c1);
+      const V3<T> refr = scale(mu, d) + scale(g, n);
       const auto tir = lt(term, zero);
       nd = refr;
       if (any_(tir)) {
@@ -593,14 +620,22 @@ DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, 
 // (elements/parent.py:44-58, rays/ray.py:29-40, elements/sensor.py:35-37).
 template <class C, class T, class M>
 DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i) {
+  const bool sensor = (S.flags & RTT_F_SENSOR) != 0;
+  if (!sensor && !any_(hit)) return;  // lanes without a hit are done; a wavefront without hits skips the block
   Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
   V3<T> nd;
   T im;
   apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im);
-  if (S.flags & RTT_F_SENSOR) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, r.I);
-  r.p = sel3(hit, fw.hit_g, r.p);
-  r.d = sel3(hit, nd, r.d);
-  r.I = sel(hit, r.I * im, r.I);
+  if (sensor) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, r.I);
+  if (__all(!any_(not_(hit)))) {  // every ray of the wavefront hits: plain moves, no selects
+    r.p = fw.hit_g;
+    r.d = nd;
+    r.I = r.I * im;
+  } else {
+    r.p = sel3(hit, fw.hit_g, r.p);
+    r.d = sel3(hit, nd, r.d);
+    r.I = sel(hit, r.I * im, r.I);
+  }
 }
 
 // test + interact of one surface (scene/sequential.py:19-34)
@@ -608,8 +643,8 @@ template <class C, class T>
 DI void visit_seq(const RttSurface& S, Ray<T>& r, const SensorIO& se, int64_t i) {
   Frames<T> f;
   T t_raw;
-  const T t = test_surface<C>(S, r.p, r.d, f, t_raw);
-  interact<C>(S, f, t_raw, lt(t, splat<T>(kInf)), r, se, i);
+  const auto hit = test_surface<C>(S, r.p, r.d, f, t_raw);
+  interact<C>(S, f, t_raw, hit, r, se, i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,8 +682,12 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops,
   for (int s = 0; s < n_surf; ++s) {
     const RttSurface& S = prog[s];
     Frames<float> f;
-    float t_raw, t;
-#define RTT_CALL(CFG) t = test_surface<CFG>(S, p, d, f, t_raw)
+    float t_raw = kInf, t = kInf;
+#define RTT_CALL(CFG)                                          \
+  {                                                            \
+    const bool valid = test_surface<CFG>(S, p, d, f, t_raw);   \
+    t = masked_t<CFG>(S, t_raw, valid);                        \
+  }
     RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     const bool take = (tmin == tmin) && ((t != t) || (t < tmin));
@@ -724,7 +763,8 @@ __global__ void __launch_bounds__(kBlock) k_intersect_test(const float* __restri
     for (int s = 0; s < n_surf; ++s) {
       Frames<float> f;
       float t_raw;
-      t_out[(int64_t)s * ld_t + i] = test_surface<CGeneric>(prog[s], p, d, f, t_raw);
+      const bool valid = test_surface<CGeneric>(prog[s], p, d, f, t_raw);
+      t_out[(int64_t)s * ld_t + i] = masked_t<CGeneric>(prog[s], t_raw, valid);
     }
   }
 }
