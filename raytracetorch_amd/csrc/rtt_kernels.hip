@@ -576,35 +576,53 @@ struct Ray {
   T I;
 };
 
-// lane type T at ray index i: float reads ray i, f2 reads rays i and i+1 with one 8-byte access
-template <class T> DI T ld_(const float* p, int64_t i) { return *reinterpret_cast<const T*>(p + i); }
-template <class T> DI void st_(float* p, int64_t i, T v) { *reinterpret_cast<T*>(p + i) = v; }
+// Lane type T at ray index i: float reads ray i; f2 reads rays i and i+1, with one 8-byte access when
+// `vec` (planes 8-byte aligned) and both rays exist, else with two 4-byte accesses; a lane holding only
+// the last ray of an odd-length bundle (nv == 1) duplicates it into its second component.
+DI float ld_(const float* p, int64_t i, bool, int, float*) { return p[i]; }
+DI f2 ld_(const float* p, int64_t i, bool vec, int nv, f2*) {
+  if (vec && nv == 2) return *reinterpret_cast<const f2*>(p + i);
+  return f2{p[i], p[i + (nv - 1)]};
+}
+DI void st_(float* p, int64_t i, float v, bool, int) { p[i] = v; }
+DI void st_(float* p, int64_t i, f2 v, bool vec, int nv) {
+  if (vec && nv == 2) {
+    *reinterpret_cast<f2*>(p + i) = v;
+  } else {
+    p[i] = v.x;
+    if (nv == 2) p[i + 1] = v.y;
+  }
+}
 
 template <class T>
-DI Ray<T> load_ray(const RayIO& io, int64_t i) {
+DI Ray<T> load_ray(const RayIO& io, int64_t i, bool vec = false, int nv = LaneOf<T>::N) {
   Ray<T> r;
-  r.p = {ld_<T>(io.pos_in, i), ld_<T>(io.pos_in + io.ld_in, i), ld_<T>(io.pos_in + 2 * io.ld_in, i)};
-  r.d = {ld_<T>(io.dir_in, i), ld_<T>(io.dir_in + io.ld_in, i), ld_<T>(io.dir_in + 2 * io.ld_in, i)};
-  r.I = ld_<T>(io.inten_in, i);
+  T* tag = nullptr;
+  r.p = {ld_(io.pos_in, i, vec, nv, tag), ld_(io.pos_in + io.ld_in, i, vec, nv, tag),
+         ld_(io.pos_in + 2 * io.ld_in, i, vec, nv, tag)};
+  r.d = {ld_(io.dir_in, i, vec, nv, tag), ld_(io.dir_in + io.ld_in, i, vec, nv, tag),
+         ld_(io.dir_in + 2 * io.ld_in, i, vec, nv, tag)};
+  r.I = ld_(io.inten_in, i, vec, nv, tag);
   return r;
 }
 
 template <class T>
-DI void store_ray(const RayIO& io, int64_t i, const Ray<T>& r) {
-  st_<T>(io.pos_out, i, r.p.x);
-  st_<T>(io.pos_out + io.ld_out, i, r.p.y);
-  st_<T>(io.pos_out + 2 * io.ld_out, i, r.p.z);
-  st_<T>(io.dir_out, i, r.d.x);
-  st_<T>(io.dir_out + io.ld_out, i, r.d.y);
-  st_<T>(io.dir_out + 2 * io.ld_out, i, r.d.z);
-  st_<T>(io.inten_out, i, r.I);
+DI void store_ray(const RayIO& io, int64_t i, const Ray<T>& r, bool vec = false, int nv = LaneOf<T>::N) {
+  st_(io.pos_out, i, r.p.x, vec, nv);
+  st_(io.pos_out + io.ld_out, i, r.p.y, vec, nv);
+  st_(io.pos_out + 2 * io.ld_out, i, r.p.z, vec, nv);
+  st_(io.dir_out, i, r.d.x, vec, nv);
+  st_(io.dir_out + io.ld_out, i, r.d.y, vec, nv);
+  st_(io.dir_out + 2 * io.ld_out, i, r.d.z, vec, nv);
+  st_(io.inten_out, i, r.I, vec, nv);
 }
 
 template <class T, class M>
-DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, T I) {
+DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, T I, int nv) {
   const int64_t base = (int64_t)slot * se.ld;
 #pragma unroll
   for (int k = 0; k < LaneOf<T>::N; ++k) {
+    if (k >= nv) break;
     const bool h = mcomp(hit, k);
     se.mask[base + i + k] = h ? 1 : 0;
     if (h) {
@@ -619,14 +637,15 @@ DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, 
 // Apply surface S to the ray(s) of a lane where hit: Element.forward + Rays.scatter_update
 // (elements/parent.py:44-58, rays/ray.py:29-40, elements/sensor.py:35-37).
 template <class C, class T, class M>
-DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i) {
+DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i,
+                 int nv = LaneOf<T>::N) {
   const bool sensor = (S.flags & RTT_F_SENSOR) != 0;
   if (!sensor && !any_(hit)) return;  // lanes without a hit are done; a wavefront without hits skips the block
   Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
   V3<T> nd;
   T im;
   apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im);
-  if (sensor) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, r.I);
+  if (sensor) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, r.I, nv);
   if (__all(!any_(not_(hit)))) {  // every ray of the wavefront hits: plain moves, no selects
     r.p = fw.hit_g;
     r.d = nd;
@@ -640,34 +659,37 @@ DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>
 
 // test + interact of one surface (scene/sequential.py:19-34)
 template <class C, class T>
-DI void visit_seq(const RttSurface& S, Ray<T>& r, const SensorIO& se, int64_t i) {
+DI void visit_seq(const RttSurface& S, Ray<T>& r, const SensorIO& se, int64_t i, int nv) {
   Frames<T> f;
   T t_raw;
   const auto hit = test_surface<C>(S, r.p, r.d, f, t_raw);
-  interact<C>(S, f, t_raw, hit, r, se, i);
+  interact<C>(S, f, t_raw, hit, r, se, i, nv);
 }
 
 // ------------------------------------------------------------------------------------------------
 // SequentialScene.simulate (scene/sequential.py:12-36)
 // T = f2: lane l of a block works on the adjacent rays (2l, 2l+1) of its tile, read and written
-// with 8-byte accesses (512 contiguous bytes per wavefront instruction); the host launches this
-// form on the even-length, 8-byte aligned part of the bundle and T = float on what is left.
+// with 8-byte accesses (512 contiguous bytes per wavefront instruction) when the planes are 8-byte
+// aligned (`vec`), with 4-byte accesses otherwise.  Every ray, including the last one of an odd-length
+// bundle, goes through the same packed arithmetic, so a ray's result does not depend on the size or
+// alignment of the batch it is traced in.
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                      Ops ops, SensorIO se) {
+                                                      Ops ops, SensorIO se, int vec) {
   constexpr int N = LaneOf<T>::N;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
   for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < io.n; i += stride) {
-    Ray<T> r = load_ray<T>(io, i);
+    const int nv = (io.n - i) >= N ? N : 1;
+    Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
     for (int s = 0; s < n_surf; ++s) {
       const RttSurface& S = prog[s];
-#define RTT_CALL(CFG) visit_seq<CFG>(S, r, se, i)
+#define RTT_CALL(CFG) visit_seq<CFG>(S, r, se, i, nv)
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     }
-    store_ray<T>(io, i, r);
+    store_ray<T>(io, i, r, vec != 0, nv);
   }
 }
 
@@ -988,29 +1010,14 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
   const Ops ops = make_ops(prog_host, n_surf);
   const hipStream_t st = (hipStream_t)stream;
-  // Packed form (two adjacent rays per lane, 8-byte accesses) on the even-length part when every plane
-  // is 8-byte aligned; one ray per lane on the remainder or on everything otherwise.
+  // two adjacent rays per lane; 8-byte accesses when every plane is 8-byte aligned
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
-  const bool can_pack = g_rays_per_lane >= 2 && (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) &&
-                        aligned8(dir_in) && aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) &&
-                        aligned8(inten_out);
-  const int64_t n_pack = can_pack ? (n & ~(int64_t)1) : 0;
-  if (n_pack > 0) {
-    RayIO io2 = io;
-    io2.n = n_pack;
-    hipLaunchKernelGGL(k_trace_seq<f2>, dim3(grid_for(n_pack, 2)), dim3(kBlock), 0, st, io2, prog_dev, n_surf, ops,
-                       se);
-  }
-  if (n_pack < n) {
-    RayIO io1 = io;
-    io1.pos_in += n_pack; io1.dir_in += n_pack; io1.inten_in += n_pack;
-    io1.pos_out += n_pack; io1.dir_out += n_pack; io1.inten_out += n_pack;
-    io1.n = n - n_pack;
-    SensorIO se1 = se;
-    if (se1.hit) { se1.hit += n_pack; se1.w += n_pack; se1.mask += n_pack; }
-    hipLaunchKernelGGL(k_trace_seq<float>, dim3(grid_for(n - n_pack, 1)), dim3(kBlock), 0, st, io1, prog_dev, n_surf,
-                       ops, se1);
-  }
+  const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
+                  aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+  if (g_rays_per_lane == 1)
+    hipLaunchKernelGGL(k_trace_seq<float>, dim3(grid_for(n, 1)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, 0);
+  else
+    hipLaunchKernelGGL(k_trace_seq<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
   return launch_status();
 }
 

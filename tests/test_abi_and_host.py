@@ -1,0 +1,258 @@
+"""CPU: the C-ABI library loads and exports what include/rtt_hip.h declares, the host-side mirror of
+the reference API behaves like the reference, and nothing falls back to a CPU computation."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from raytracetorch_amd import _native, program as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rtt_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.lib()
+    names = declared_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in rtt_hip.h but not exported"
+    assert set(names) == set(_native.EXPORTS)
+    assert lib.rtt_abi_version() == 1
+    assert lib.rtt_surface_record_bytes() == 256 == P.RECORD_BYTES
+
+
+def test_record_layout_matches_header():
+    """Field offsets of the numpy record equal offsetof() of the C struct."""
+    fields = [n for n in P.SURFACE_DTYPE.names if n != "pad"]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"rtt_hip.h\"\nint main(){\n"
+    for f in fields:
+        prog += f'  printf("{f} %zu\\n", offsetof(RttSurface, {f}));\n'
+    prog += '  printf("sizeof %zu\\n", sizeof(RttSurface));\n  return 0;\n}\n'
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "o.c"), os.path.join(d, "o")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    for f in fields:
+        assert int(out[f]) == P.SURFACE_DTYPE.fields[f][1], f
+    assert int(out["sizeof"]) == 256
+
+
+def test_entry_points_validate_before_touching_the_gpu():
+    """Argument errors are reported as codes; no kernel is launched (this runs without a GPU)."""
+    lib = _native.lib()
+    rec = P.new_record()[None].copy()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    hp = rec.ctypes.data
+    E_NULL, E_SIZE, E_KIND, E_ALIGN = -1, -2, -3, -5
+    assert lib.rtt_trace_seq_f32(0, p, p, 8, p, p, p, 8, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_NULL
+    assert lib.rtt_trace_seq_f32(p, p, p, 4, p, p, p, 8, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_SIZE      # ld < n
+    assert lib.rtt_trace_seq_f32(p, p, p, 8, p, p, p, 8, 8, p, hp, 0, 0, 0, 0, 0, 0) == E_SIZE      # n_surf < 1
+    assert lib.rtt_trace_seq_f32(p, p, p, 8, p, p, p, 8, 8, p, hp, 65, 0, 0, 0, 0, 0) == E_SIZE     # n_surf > 64
+    assert lib.rtt_trace_seq_f32(p + 2, p, p, 8, p, p, p, 8, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_ALIGN
+    bad = rec.copy(); bad["surf_kind"] = 17
+    assert lib.rtt_trace_seq_f32(p, p, p, 8, p, p, p, 8, 8, p, bad.ctypes.data, 1, 0, 0, 0, 0, 0) == E_KIND
+    sens = rec.copy(); sens["flags"] |= P.F_SENSOR; sens["sensor_slot"] = 0
+    assert lib.rtt_trace_seq_f32(p, p, p, 8, p, p, p, 8, 8, p, sens.ctypes.data, 1, 0, 0, 0, 8, 0) == E_NULL  # no sensor buffers
+    assert lib.rtt_trace_seq_f32(p, p, p, 8, p, p, p, 8, 0, p, hp, 1, 0, 0, 0, 0, 0) == 0            # n == 0: nothing to do
+    assert lib.rtt_ray_cast_f32(p, p, 8, 0, p, hp, 1, 0, 0, 0) == 0
+    assert lib.rtt_intersect_test_f32(p, p, 8, 8, p, hp, 1, 0, 8, 0) == E_NULL
+    assert lib.rtt_surface_forward_f32(p, p, 8, 8, p, hp, 64, 0, 0, 0, 0, 0, 0, 8, 0) == E_SIZE
+    assert lib.rtt_spot_moments_f32(p, p, p, 0, 8, 2, 0.0, 0.0, 1.0, p, 0) == E_SIZE
+    assert lib.rtt_strerror(E_KIND).decode().startswith("surface record")
+    assert lib.rtt_tune(0, 3) == E_SIZE and lib.rtt_tune(0, 2) == 0
+
+
+def test_no_cpu_fallback(ns):
+    """CPU tensors are refused loudly by every compute entry of the product API."""
+    torch.manual_seed(0)
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    rays = scenes.disk_bundle(ns).sample(16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ns.SequentialScene([lens, sensor]).simulate(rays)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lens.intersectTest(rays)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lens(rays, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lens.shape.surfaces[0](rays)
+    scene = ns.Scene(); scene.add_element(lens); scene.rays = rays
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scene.step()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ns.RefractSnell(1.0, 1.5)(rays.pos, rays.dir, rays.dir)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/librtt_hip.so")
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "raytracetorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "rtt_oracle" not in src and "import oracle" not in src and "ref_loader" not in src, f
+
+
+# ---- Rays container (rays/ray.py:7-97 of the reference) -------------------------------------------
+def test_rays_container_semantics(ns):
+    r = ns.Rays.initialize([[0, 0, -10], [1, 1, -5], [2, 0, 0]], [[0, 0, 2], [0, 3, 4], [0, 0, 0]], ray_id=5)
+    assert r.pos.shape == (3, 3) and r.dir.shape == (3, 3) and r.batch_size == torch.Size([3])
+    assert r.id.dtype == torch.int8 and int(r.id[0]) == 5
+    assert torch.equal(r.intensity, torch.ones(3)) and torch.equal(r.wavelength, torch.zeros(3))
+    assert torch.allclose(r.dir, torch.tensor([[0, 0, 1.0], [0, 0.6, 0.8], [0, 0, 0]]))  # normalised, zero stays zero
+    assert r._pos.is_contiguous() and r._pos.shape == (3, 3)  # planes
+    assert r.pos.data_ptr() == r._pos.data_ptr()  # [N,3] view, no copy
+    sub = r[torch.tensor([True, False, True])]
+    assert sub.pos.shape == (2, 3) and torch.equal(sub.pos[1], torch.tensor([2.0, 0, 0]))
+    r.scatter_update(torch.tensor([False, True, False]), torch.tensor([[9.0, 9, 9]]), torch.tensor([[0.0, 2, 0]]),
+                     torch.tensor([0.5]))
+    assert torch.equal(r.pos[1], torch.tensor([9.0, 9, 9])) and torch.equal(r.dir[1], torch.tensor([0.0, 2, 0]))
+    assert torch.equal(r.intensity, torch.tensor([1.0, 0.5, 1.0]))
+    w = r.with_coords(r.pos + 1, r.dir * 3)
+    assert torch.allclose(w.dir[1], torch.tensor([0.0, 1.0, 0.0])) and w.intensity is r.intensity
+    r.pos = torch.zeros(3, 3)
+    assert torch.equal(r._pos, torch.zeros(3, 3))
+    with pytest.raises(ValueError):
+        ns.Rays(pos=torch.zeros(3, 3), dir=torch.zeros(3, 3), intensity=torch.ones(3), id=torch.zeros(3),
+                wavelength=torch.zeros(3), batch_size=[4])
+
+
+def test_bundles_sample_expected_geometry(ns):
+    torch.manual_seed(0)
+    r = scenes.disk_bundle(ns, radius=4.0, z=-30.0).sample(20000)
+    rad = r.pos[:, :2].norm(dim=1)
+    assert rad.max() <= 4.0 and torch.all(r.pos[:, 2] == -30.0) and torch.all(r.dir[:, 2] == 1.0)
+    assert abs(float((rad < 2.0).float().mean()) - 0.25) < 0.02  # uniform in area
+    tilted = scenes.disk_bundle(ns, rot=[-0.087, 0.0, 0.0]).sample(8)
+    assert torch.allclose(tilted.dir[:, 1], torch.full((8,), float(np.sin(0.087))), atol=1e-6)
+    ps = ns.PointSource(NA=0.5, ray_id=1).sample(5000)
+    assert torch.allclose(ps.dir.norm(dim=1), torch.ones(5000), atol=1e-6) and ps.dir[:, 2].min() >= np.sqrt(0.75) - 1e-6
+    fan = ns.Fan(angle=0.4, ray_id=0).sample(100)
+    assert torch.all(fan.dir[:, 0] == 0) and fan.dir[:, 1].abs().max() <= np.sin(0.2) + 1e-6
+    line = ns.CollimatedLine(length=2.0, ray_id=0).sample(100)
+    assert line.pos[:, 0].abs().max() <= 2.0 and torch.all(line.pos[:, 1:] == 0)
+
+
+# ---- scene compiler ------------------------------------------------------------------------------------
+def test_singlet_program(ns):
+    lens = scenes.singlet(ns, transform=scenes.T(ns, 7.0))
+    prog = P.compile_elements([lens])
+    assert prog.shape == (3,) and prog.dtype == P.SURFACE_DTYPE
+    assert list(prog["surf_kind"]) == [P.SURF_QUADRIC, P.SURF_QUADRIC, P.SURF_CYLINDER]
+    assert list(prog["bound_kind"]) == [P.BND_HALF, P.BND_HALF, P.BND_NONE]
+    assert list(prog["shape_kind"]) == [P.SHP_SPHERIC_FACE, P.SHP_SPHERIC_FACE, P.SHP_SPHERIC_EDGE]
+    assert list(prog["phys_kind"]) == [P.PHYS_SNELL, P.PHYS_SNELL, P.PHYS_BLOCK]
+    allid = P.F_HAS_SHAPE | P.F_SHAPE_ROT_ID | P.F_SURF_ROT_ID
+    assert all(int(f) == allid for f in prog["flags"])
+    assert np.allclose(prog["ts"], [[0, 0, 7.0]] * 3)
+    assert np.allclose(prog["tj"][:, 2], [-1.5, 1.5, 0.0])
+    # elements/lens.py:41-49: front face ior_in = glass, ior_out = media; back face the other way round
+    assert np.allclose(prog["phys"][0], [1.5, 1.0, 1.0 / 1.5, 1.5])
+    assert np.allclose(prog["phys"][1], [1.0, 1.5, 1.5, 1.0 / 1.5])
+    assert np.allclose(prog["geom"][0][:3], [0.05, 0.0, 0.05]) and np.allclose(prog["geom"][2][:2], [5.0, 25.0])
+    assert np.isclose(prog["shp"][0][0], 25.0)
+    sag = 0.05 * 25 / (1 + np.sqrt(1 - 0.05 ** 2 * 25))
+    assert np.allclose(prog["shp"][2][:2], [sag - 1.5, 1.5 - sag], atol=1e-6)
+
+
+def test_program_tracks_live_parameters(ns):
+    lens = scenes.singlet(ns, c1_grad=True)
+    a = P.compile_elements([lens])
+    with torch.no_grad():
+        lens.shape.surfaces[0].c.fill_(0.02)
+        lens.ior_glass.fill_(1.7)
+    b = P.compile_elements([lens])
+    assert np.isclose(b["geom"][0][0], 0.02) and not np.isclose(a["geom"][0][0], 0.02)
+    assert np.isclose(b["phys"][0][0], 1.7) and np.isclose(b["phys"][1][1], 1.7)  # shared Parameter on both faces
+
+
+def test_system_and_naive_programs(ns):
+    prog = P.compile_elements(scenes.system5(ns))
+    assert prog.shape[0] == 9
+    assert list(prog["element_id"]) == [0, 0, 0, 1, 2, 2, 2, 3, 4]
+    stop = prog[3]
+    assert stop["surf_kind"] == P.SURF_PLANE and stop["bound_kind"] == P.BND_DISK and stop["phys_kind"] == P.PHYS_APERTURE
+    assert int(stop["flags"]) & P.F_INVERT and not int(stop["flags"]) & P.F_HAS_SHAPE
+    mirror = prog[7]
+    assert mirror["bound_kind"] == P.BND_HALF_DISK and mirror["phys_kind"] == P.PHYS_REFLECT and np.isclose(mirror["bnd"][0], 225.0)
+    sensor = prog[8]
+    assert int(sensor["flags"]) & P.F_SENSOR and sensor["sensor_slot"] == 0 and P.n_sensor_slots(prog) == 1
+    prog = P.compile_elements(scenes.naive32(ns))
+    assert prog.shape[0] == 32
+    side = prog[20]  # first side plane of the first cylindrical singlet
+    assert side["surf_kind"] == P.SURF_PLANE and side["shape_kind"] == P.SHP_CYL_EDGE
+    assert not int(side["flags"]) & P.F_SURF_ROT_ID and int(side["flags"]) & P.F_SHAPE_ROT_ID
+    assert np.allclose(side["shp"][:4], [7.00001, -7.00001, 7.00001, -7.00001], atol=1e-6)
+
+
+def test_constructor_validation(ns):
+    with pytest.raises(ValueError, match="R1"):
+        ns.SingletLens(c1=0.5, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5)
+    with pytest.raises(ValueError, match="Thickness"):
+        ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=0.0, ior_glass=1.5)
+    with pytest.raises(ValueError, match="ntersect"):
+        ns.SingletLens(c1=0.15, c2=-0.15, d=10.0, t=0.5, ior_glass=1.5)
+    with pytest.raises(NotImplementedError):
+        ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5, fresnel=True)
+    too_many = [scenes.singlet(ns) for _ in range(22)]
+    with pytest.raises(ValueError, match="at most"):
+        P.compile_elements(too_many)
+
+
+def test_scene_bookkeeping(ns):
+    scene = ns.Scene()
+    assert scene.total_surfaces == 0 and scene.ray_cast(None) is None
+    els = scenes.system5(ns)
+    for el in els:
+        scene.add_element(el)
+    scene._build_index_maps()
+    assert scene.total_surfaces == 9
+    assert scene.map_to_element.tolist() == [0, 0, 0, 1, 2, 2, 2, 3, 4] and scene.map_to_surface.tolist() == [0, 1, 2, 0, 0, 1, 2, 0, 0]
+    seq = scene.to_sequential()
+    zs = [float(e.shape.transform.trans[2]) for e in seq.elements]
+    assert zs == sorted(zs) and isinstance(seq, ns.SequentialScene)
+    assert len(seq.to_base().elements) == 5
+    torch.manual_seed(0)
+    scene.add_bundle(scenes.disk_bundle(ns), 10)
+    scene.add_bundle(scenes.disk_bundle(ns, ray_id=3), 6)
+    scene._build_rays()
+    assert len(scene.rays) == 16 and scene.rays.id.tolist() == [0] * 10 + [3] * 6
+    scene.clear_bundles()
+    assert scene.rays is None
+
+
+def test_sensor_lists(ns):
+    s = ns.Sensor(ns.Disk(5.0))
+    hit = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    s._record_dense(hit, torch.tensor([1.0, 0.5, 0.0, 2.0]), torch.tensor([1, 0, 1, 1], dtype=torch.uint8),
+                    torch.tensor([0, 0, 1, 1], dtype=torch.int8))
+    s._record_dense(hit, torch.ones(4), torch.zeros(4, dtype=torch.uint8), torch.zeros(4, dtype=torch.int8))
+    locs, w, ids = s.getHitsTensors()
+    assert locs.tolist() == [[0, 4, 8], [2, 6, 10], [3, 7, 11]] and w.tolist() == [1.0, 0.0, 2.0] and ids.tolist() == [0, 1, 1]
+    assert len(s.hitLocs) == 1  # the visit nobody hit leaves no entry, like the reference's `continue`
+    assert s.getHitsTensors(ray_id=1)[0].shape == (2, 3)
+    spot, wsum = s.getSpotSizeParallel_xy([1, 0])
+    assert wsum.tolist() == [1.0, 2.0]
+    s.reset()
+    assert s.hitLocs == []

@@ -1,0 +1,193 @@
+"""GPU: the configurations at their full sizes (singlet 2^20 and 64*2^20 rays, 5-element system
+16*2^20 rays, 32-surface nearest-hit step 4*2^20 rays), checked through properties that do not need
+a full-size CPU run: oracle parity on a strided sample, batch-position invariance, determinism,
+in-place == out-of-place, geometric invariants; plus ragged and degenerate sizes."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import rtt_oracle as O
+import scenes
+from util import PARITY_TOL, assert_parity
+
+import raytracetorch_amd.program as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def device_disk_rays(ns, n, seed, radius=4.0, z=-30.0, tilt=0.0):
+    """Collimated disk bundle built directly as [3,N] planes on the device."""
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    theta = torch.rand(n, device=DEV, generator=g) * (2 * math.pi)
+    r = torch.sqrt(torch.rand(n, device=DEV, generator=g) * (radius * radius))
+    pos = torch.stack([r * torch.cos(theta), r * torch.sin(theta), torch.full_like(r, z)]).contiguous()
+    d = torch.zeros((3, n), device=DEV)
+    d[1].fill_(math.sin(tilt)); d[2].fill_(math.cos(tilt))
+    return ns.Rays.from_planes(pos, d, torch.ones(n, device=DEV), torch.zeros(n, device=DEV, dtype=torch.int8),
+                               torch.zeros(n, device=DEV))
+
+
+def sample_rays(ns, rays, idx):
+    return ns.Rays.from_planes(rays._pos[:, idx].contiguous(), rays._dir[:, idx].contiguous(),
+                               rays.intensity[idx].contiguous(), rays.id[idx].contiguous(), rays.wavelength[idx].contiguous())
+
+
+def check_against_oracle(prog, rays_in, rays_out, idx, what):
+    p, d, I = rays_in.pos[idx].cpu().numpy(), rays_in.dir[idx].cpu().numpy(), rays_in.intensity[idx].cpu().numpy()
+    o32 = O.trace_sequential(prog, p, d, I)
+    o64 = O.trace_sequential(prog, p, d, I, dtype=torch.float64)
+    got_I = rays_out.intensity[idx].cpu().numpy()
+    assert np.array_equal(got_I > 0, o32["intensity"].numpy() > 0), what
+    assert_parity(rays_out.pos[idx].cpu().numpy(), o32["pos"].numpy(), o64["pos"].numpy(), what=what + " pos")
+    assert_parity(rays_out.dir[idx].cpu().numpy(), o32["dir"].numpy(), o64["dir"].numpy(), what=what + " dir")
+
+
+@pytest.mark.parametrize("n", [2 ** 20, 64 * 2 ** 20])
+def test_singlet_full_size(ns, n):
+    lens = scenes.singlet(ns)
+    scene = ns.SequentialScene([lens])
+    prog = P.compile_elements([lens])
+    rays = device_disk_rays(ns, n, seed=7, radius=5.5, tilt=0.02)  # some rays miss the aperture / hit the edge
+    out = rays.clone()
+    scene.simulate(rays, out=out)
+    idx = torch.arange(0, n, max(1, n // 65536), device=DEV)[:65536]
+    check_against_oracle(prog, rays, out, idx, f"singlet n={n}")
+    # determinism and in-place == out-of-place
+    out2 = rays.clone()
+    scene.simulate(out2)
+    assert torch.equal(out2._pos, out._pos) and torch.equal(out2._dir, out._dir) and torch.equal(out2.intensity, out.intensity)
+    # batch-position invariance: the same rays traced as a small batch give the same bits
+    sub = sample_rays(ns, rays, idx)
+    scene.simulate(sub)
+    assert torch.equal(sub._pos, out._pos[:, idx]) and torch.equal(sub._dir, out._dir[:, idx])
+    # invariants: live rays sit on the back surface c(x^2+y^2) + c z'^2 - 2 z' = 0 (z' from its vertex), dead rays
+    # have zero direction, live directions are unit vectors
+    alive = out.intensity > 0
+    assert 0.3 < float(alive.float().mean()) < 1.0
+    through = alive & (out._pos[2] > -29.0)  # rays outside the aperture never move
+    assert 0.3 < float(through.float().mean())
+    x, y, z = out._pos[0][through], out._pos[1][through], out._pos[2][through]
+    zb, zf = z - 1.5, z + 1.5
+    res_back = -0.05 * (x * x + y * y) - 0.05 * zb * zb - 2 * zb
+    res_front = 0.05 * (x * x + y * y) + 0.05 * zf * zf - 2 * zf   # refracted by the front face, missed the back one
+    assert float(torch.minimum(res_back.abs(), res_front.abs()).max()) < 1e-4
+    assert float((res_back.abs() < 1e-4).float().mean()) > 0.9
+    nrm = torch.sqrt((out._dir[:, alive] ** 2).sum(0))
+    assert float((nrm - 1).abs().max()) < 1e-5
+    assert float(out._dir[:, ~alive].abs().max()) == 0.0
+
+
+def test_system5_full_size(ns):
+    n = 16 * 2 ** 20
+    elements = scenes.system5(ns)
+    scene = ns.SequentialScene(elements)
+    prog = P.compile_elements(elements)
+    rays = device_disk_rays(ns, n, seed=11)
+    out = rays.clone()
+    scene.simulate(rays, out=out)
+    idx = torch.arange(0, n, n // 65536, device=DEV)[:65536]
+    check_against_oracle(prog, rays, out, idx, "system5")
+    sensor = elements[-1]
+    hit, w, mask, ids = sensor._dense[0]
+    o32 = O.trace_sequential(prog, rays.pos[idx].cpu().numpy(), rays.dir[idx].cpu().numpy(), rays.intensity[idx].cpu().numpy())
+    _, omask, ohl, ow = o32["sensor"][0]
+    assert np.array_equal(mask[idx].cpu().numpy().astype(bool), omask.numpy())
+    m = omask.numpy()
+    assert_parity(hit[:, idx].t().cpu().numpy()[m], ohl.numpy()[m], what="system5 sensor hit_local")
+    assert np.array_equal(w[idx].cpu().numpy()[m], ow.numpy()[m])
+    # the stop zeroes rays outside r=3.5 at z=5; all recorded sensor hits lie inside the sensor disk
+    live = mask.bool() & (w > 0)
+    assert float((hit[0][live] ** 2 + hit[1][live] ** 2).max()) <= 400.0
+    scene.simulate(rays)  # in place
+    assert torch.equal(rays._pos, out._pos) and torch.equal(rays.intensity, out.intensity)
+
+
+def test_naive32_full_size(ns):
+    n = 4 * 2 ** 20
+    scene = ns.Scene()
+    for el in scenes.naive32(ns):
+        scene.add_element(el)
+    prog = P.compile_elements(scene.elements)
+    rays = device_disk_rays(ns, n, seed=13, radius=6.5, z=-10.0, tilt=0.03)
+    # second half of the bundle starts between the lenses pointing backwards / sideways
+    h = n // 2
+    rays._pos[2, h:] = 44.5
+    rays._dir[:, h:] = torch.nn.functional.normalize(torch.randn(3, n - h, device=DEV), dim=0)
+    before = rays.clone()
+    hit, el_ids, sf_ids = scene.ray_cast(rays)
+    idx = torch.arange(0, n, n // 32768, device=DEV)[:32768]
+    p, d, I = before.pos[idx].cpu().numpy(), before.dir[idx].cpu().numpy(), before.intensity[idx].cpu().numpy()
+    tmin, win, tm = O.ray_cast(prog, p, d)
+    srt = np.sort(tm.numpy(), axis=1)
+    tie = np.isfinite(srt[:, 1]) & (np.abs(srt[:, 1] - srt[:, 0]) <= 1e-4 * np.abs(srt[:, 0]))
+    assert tie.mean() < 0.01
+    ok = ~tie
+    assert np.array_equal(hit[idx].cpu().numpy()[ok], (win.numpy() >= 0)[ok])
+    both = ok & (win.numpy() >= 0)
+    assert np.array_equal(el_ids[idx].cpu().numpy()[both], prog["element_id"][win.numpy()[both]])
+    assert np.array_equal(sf_ids[idx].cpu().numpy()[both], prog["surface_id"][win.numpy()[both]])
+    assert len(np.unique(win.numpy())) >= 8  # the bundle exercises many different winners
+    scene.rays = rays
+    scene.step()
+    o = O.step_nearest(prog, p, d, I)
+    o64 = O.step_nearest(prog, p, d, I, dtype=torch.float64)
+    same = ok & (o64["winner"].numpy() == o["winner"].numpy())
+    assert_parity(rays.pos[idx].cpu().numpy()[same], o["pos"].numpy()[same], o64["pos"].numpy()[same], what="naive step pos")
+    assert_parity(rays.dir[idx].cpu().numpy()[same], o["dir"].numpy()[same], o64["dir"].numpy()[same], what="naive step dir")
+    assert np.array_equal((rays.intensity[idx].cpu().numpy() > 0)[same], (o["intensity"].numpy() > 0)[same])
+    # a second bounce runs and leaves rays that missed everything untouched
+    miss = ~hit
+    snap = rays._pos[:, miss].clone()
+    scene.step()
+    assert torch.equal(rays._pos[:, miss], snap)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 513, 4097])
+def test_ragged_sizes(ns, n):
+    """Every batch size takes the same per-ray result (odd lengths, unaligned planes, empty)."""
+    elements = list(scenes.spot_system(ns, grads=False))
+    scene = ns.SequentialScene(elements)
+    big = device_disk_rays(ns, 8192, seed=3, radius=5.5)
+    ref = big.clone()
+    scene.simulate(ref)
+    ref_mask = elements[1]._dense[0][2].clone()
+    elements[1].reset()
+    sub = sample_rays(ns, big, torch.arange(n, device=DEV))
+    r = scene.simulate(sub)
+    assert len(r) == n
+    if n:
+        assert torch.equal(r._pos, ref._pos[:, :n]) and torch.equal(r._dir, ref._dir[:, :n])  # bit for bit
+        assert torch.equal(r.intensity, ref.intensity[:n])
+        locs, w, ids = elements[1].getHitsTensors() if elements[1].hitLocs else (torch.zeros(0, 3), None, None)
+        assert locs.shape[0] == int(ref_mask[:n].sum())
+    # odd offsets into a larger allocation (planes not 8-byte aligned) run the one-ray-per-lane kernel
+    if n >= 3:
+        view = ns.Rays.from_planes(big._pos[:, 1:n].contiguous(), big._dir[:, 1:n].contiguous(), big.intensity[1:n].clone(),
+                                   big.id[1:n], big.wavelength[1:n])
+        scene.simulate(view)
+        assert torch.equal(view._pos, ref._pos[:, 1:n]) and torch.equal(view._dir, ref._dir[:, 1:n])
+    if n >= 4:
+        # planes that are not 8-byte aligned (odd leading dimension) take the 4-byte access path
+        m = n - 1 if (n - 1) % 2 == 1 else n - 2
+        odd = sample_rays(ns, big, torch.arange(1, 1 + m, device=DEV))
+        assert m % 2 == 1
+        scene.simulate(odd)
+        assert torch.equal(odd._pos, ref._pos[:, 1:1 + m]) and torch.equal(odd._dir, ref._dir[:, 1:1 + m])
+
+
+def test_scene_simulate_multi_bounce_terminates(ns):
+    """Scene.simulate bounces until nothing is lit or Nbounces is reached (scene/base.py:129-142)."""
+    scene = ns.Scene()
+    for el in (scenes.singlet(ns), ns.Sensor(ns.Disk(6.0, transform=scenes.T(ns, 19.0)))):
+        scene.add_element(el)
+    torch.manual_seed(0)
+    scene.add_bundle(scenes.disk_bundle(ns), 4096)
+    scene.Nbounces = 6
+    scene._build_rays()
+    scene.rays = scene.rays.to(DEV)
+    scene.simulate()
+    assert torch.isfinite(scene.rays.pos).all()
+    assert scene.elements[1].hitLocs  # something reached the sensor
