@@ -106,6 +106,20 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
                       float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
                       void* stream);
 
+/* ---- backward of the sequential trace w.r.t. scene parameters (what torch autograd does to
+ * scene/sequential.py:12-36 when c, k, trans, rot_vec, ior_* carry requires_grad; reached in the
+ * reference through optim/goals.py:144-187 and tests/test_optimize_singlet.py:66-116).
+ * Forward-mode: each ray is re-traced with n_theta (4 or 8) parameter directions; tan_dev is
+ * [n_surf][32][n_theta] = d(record slot)/d(theta_k) for the slots Rs[9], ts[3], Rj[9], tj[3], geom[4],
+ * phys[4] in that order.  The per-ray tangents are contracted with the upstream adjoints of the output
+ * rays (adj_pos, adj_dir: plane triples, nullable) and of the recorded sensor hit points
+ * (adj_sens[(3*slot+c)*sens_ld + i], nullable) and summed into dtheta[n_theta] (float64, device,
+ * zeroed by the caller). */
+int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                              const float* tan_dev, int n_theta, const float* adj_pos, const float* adj_dir,
+                              int64_t ld_adj, const float* adj_sens, int64_t sens_ld, double* dtheta, void* stream);
+
 /* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
  * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
  * tmin[i] = that t.  Either output may be NULL. */

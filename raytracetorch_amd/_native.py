@@ -24,6 +24,8 @@ _dbl = ctypes.c_double
 _SIGNATURES = {
     "rtt_trace_seq_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                           _vp, _vp, _vp, _i64, _vp],
+    "rtt_trace_seq_tangent_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64,
+                                  _vp, _vp],
     "rtt_ray_cast_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp],
     "rtt_step_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                              _vp, _vp, _vp, _vp, _i64, _vp],

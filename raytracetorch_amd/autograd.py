@@ -1,0 +1,217 @@
+"""Autograd for the device trace: gradients of anything computed from the traced rays / sensor hits
+with respect to the scene's trainable parameters.
+
+The reference gets these by letting torch autograd record every elementwise op of the trace
+(hundreds of saved [N] tensors per surface visit).  Here the trace is one kernel, so the backward is
+one kernel as well: ``rtt_trace_seq_tangent_f32`` re-traces every ray with dual numbers — forward
+mode over up to 8 parameter directions at a time — and contracts the per-ray tangents with the
+upstream adjoints on the fly.  Nothing per-ray is saved between forward and backward except the
+input bundle itself.
+
+Host side, the derivative of each packed record slot with respect to each trainable scalar
+(d(c(1+k))/dc, dR/d(rot_vec), d(n_out/n_in)/d(n_in), shared Parameters, ...) is obtained by building
+the differentiable slots as tiny torch expressions (`_diff_slots`) and asking torch for their Jacobian.
+"""
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import kernels as K
+from . import program as P
+
+TAN_SLOTS = 32  # Rs[9] ts[3] Rj[9] tj[3] geom[4] phys[4]
+_SLOT_ORDER = (("Rs", 9), ("ts", 3), ("Rj", 9), ("tj", 3), ("geom", 4), ("phys", 4))
+
+
+def trainable_scalars(elements) -> List[Tuple[torch.nn.Parameter, int]]:
+    """(parameter, flat index) for every trainable scalar of the elements, shared Parameters once.
+    Components that a gradient mask (trans_mask / rot_mask) zeroes anyway are skipped."""
+    seen, out = set(), []
+    for el in elements:
+        masks = {}
+        for mod in el.modules():
+            for name in ("trans", "rot_vec"):
+                p = getattr(mod, name, None)
+                m = getattr(mod, name.split("_")[0] + "_mask", None)
+                if isinstance(p, torch.nn.Parameter) and m is not None:
+                    masks[id(p)] = m
+        for p in el.parameters():
+            if not p.requires_grad or id(p) in seen:
+                continue
+            seen.add(id(p))
+            mask = masks.get(id(p))
+            for i in range(p.numel()):
+                if mask is None or float(mask.reshape(-1)[i]) != 0.0:
+                    out.append((p, i))
+    return out
+
+
+def tangent_table(elements, thetas) -> np.ndarray:
+    """[n_surf, 32, n_theta] float32: d(record slot)/d(theta_k), by torch autograd on the slot expressions."""
+    rows = []  # (surface index, slot offset, tensor)
+    s = 0
+    for el in elements:
+        for j in range(len(el.shape)):
+            slots = el._diff_slots(j)
+            off = 0
+            for name, width in _SLOT_ORDER:
+                t = slots.get(name)
+                if t is not None and t.requires_grad:
+                    rows.append((s, off, t.reshape(-1).to(torch.float32)))
+                off += width
+            s += 1
+    table = np.zeros((s, TAN_SLOTS, len(thetas)), dtype=np.float32)
+    if not rows or not thetas:
+        return table
+    params, index_of = [], {}
+    for p, _ in thetas:
+        if id(p) not in index_of:
+            index_of[id(p)] = len(params)
+            params.append(p)
+    y = torch.cat([r[2].cpu() for r in rows])
+    eye = torch.eye(y.numel(), dtype=y.dtype)
+    jac = torch.autograd.grad(y, params, grad_outputs=eye, is_grads_batched=True, allow_unused=True)
+    jac = [None if g is None else g.reshape(y.numel(), -1).cpu().numpy() for g in jac]
+    pos = 0
+    for surf, off, t in rows:
+        w = t.numel()
+        for k, (p, i) in enumerate(thetas):
+            g = jac[index_of[id(p)]]
+            if g is not None:
+                table[surf, off:off + w, k] = g[pos:pos + w, i]
+        pos += w
+    return table
+
+
+def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
+    """sum_i <adjoint_i, d out_i / d theta_k> for all theta, in chunks of 8 (or 4) directions."""
+    n = len(rays_in)
+    dev = rays_in.device
+    n_theta = table.shape[2]
+    out = torch.zeros(n_theta, dtype=torch.float64, device=dev)
+    if n == 0 or n_theta == 0:
+        return out
+    dp = N.DeviceProgram.upload(prog, dev)
+    fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
+    adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
+    for k0 in range(0, n_theta, 8):
+        chunk = table[:, :, k0:k0 + 8]
+        width = 4 if chunk.shape[2] <= 4 else 8
+        padded = np.zeros((table.shape[0], TAN_SLOTS, width), dtype=np.float32)
+        padded[:, :, :chunk.shape[2]] = chunk
+        tan_dev = torch.from_numpy(padded).to(dev)
+        acc = torch.zeros(width, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_trace_seq_tangent_f32(
+                N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width,
+                N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n, N.ptr(acc), N.stream_handle(dev))
+        N.check(code, "rtt_trace_seq_tangent_f32")
+        out[k0:k0 + chunk.shape[2]] = acc[:chunk.shape[2]]
+    return out
+
+
+class TraceSeqFn(torch.autograd.Function):
+    """SequentialScene.simulate as a differentiable function of the scene parameters.
+
+    forward(rays_in, prog, table, thetas, group, *params) -> (pos planes, dir planes, intensity,
+    sens_hit, sens_w, sens_mask); only pos, dir and sens_hit carry gradient."""
+
+    @staticmethod
+    def forward(ctx, rays_in, prog, table, thetas, group, *params):
+        from .rays.ray import Rays
+        out = rays_in.clone()
+        sens_hit, sens_w, sens_mask = K.trace_sequential(rays_in, prog, out=out)
+        ctx.rays_in, ctx.prog, ctx.table, ctx.thetas, ctx.group = rays_in, prog, table, thetas, group
+        ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
+        ctx.param_ids = [id(p) for p in params]
+        ctx.set_materialize_grads(False)
+        empty = torch.empty(0, device=rays_in.device)
+        outs = (out._pos, out._dir, out.intensity, sens_hit if sens_hit is not None else empty,
+                sens_w if sens_w is not None else empty, sens_mask if sens_mask is not None else empty)
+        ctx.mark_non_differentiable(outs[2], outs[4], outs[5])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_pos, g_dir, _gi, g_sens, _gw, _gm):
+        if g_sens is not None and g_sens.numel() == 0:
+            g_sens = None
+        dtheta = _tangent_contract(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens)
+        if ctx.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(dtheta, op=dist.ReduceOp.SUM, group=ctx.group)
+        grads = [torch.zeros(shape, dtype=torch.float64, device=dtheta.device) for shape, _, _ in ctx.param_meta]
+        where = {pid: k for k, pid in enumerate(ctx.param_ids)}
+        for k, (p, i) in enumerate(ctx.thetas):
+            grads[where[id(p)]].view(-1)[i] = dtheta[k]
+        grads = [g.to(device=dev, dtype=dt) for g, (_, dt, dev) in zip(grads, ctx.param_meta)]
+        return (None, None, None, None, None, *grads)
+
+
+def needs_grad(elements) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for el in elements for p in el.parameters())
+
+
+def trace_sequential_with_grad(elements, rays, prog, group=None):
+    """Run the differentiable trace; returns the six outputs of TraceSeqFn."""
+    thetas = trainable_scalars(elements)
+    table = tangent_table(elements, thetas)
+    params, seen = [], set()
+    for p, _ in thetas:
+        if id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    return TraceSeqFn.apply(rays, prog, table, thetas, group, *params)
+
+
+class SpotLossFn(torch.autograd.Function):
+    """sum_i sqrt(((x_i-cx)^2 + (y_i-cy)^2) w_i / W) over entries with mask and w > 0
+    (optim/goals.py:165-183), W and the centroid summed over all ranks of `group` when given.
+
+    The value comes from the float64 moment kernels; the backward is the closed form
+      dL/dx_i = g_i - (w_i / W) sum_j g_j  (centroid mode),  g_i = (x_i - cx) (w_i / W) / u_i,
+    and w carries no gradient (it is the 0/1 intensity, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, x, y, w, mask, target, group):
+        mom = torch.zeros(4, device=x.device, dtype=torch.float64)
+        xc, yc, wc = x.detach().contiguous(), y.detach().contiguous(), w.contiguous()
+        K.spot_moments(xc, yc, wc, mask, 0, 0.0, 0.0, 1.0, mom)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=group)
+        W, Sx, Sy, _ = mom.tolist()
+        W = max(W, 1e-12)
+        cx, cy = (Sx / W, Sy / W) if target is None else (float(target[0]), float(target[1]))
+        K.spot_moments(xc, yc, wc, mask, 1, cx, cy, W, mom)
+        loss = mom[3:4].clone()
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+        ctx.save_for_backward(xc, yc, wc, mask)
+        ctx.consts = (cx, cy, W, target is None, group)
+        return loss.reshape(()).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w, mask = ctx.saved_tensors
+        cx, cy, W, centroid, group = ctx.consts
+        act = w > 0
+        if mask is not None:
+            act = act & mask.bool()
+        wn = torch.where(act, w, torch.zeros_like(w)) / W
+        dx = torch.where(act, x - cx, torch.zeros_like(x))
+        dy = torch.where(act, y - cy, torch.zeros_like(y))
+        u = torch.sqrt((dx * dx + dy * dy) * wn)
+        inv = torch.where(u > 0, wn / u, torch.zeros_like(u))
+        gx, gy = dx * inv, dy * inv
+        if centroid:
+            G = torch.stack([gx.sum(dtype=torch.float64), gy.sum(dtype=torch.float64)])
+            if group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+            gx = gx - wn * G[0].to(gx.dtype)
+            gy = gy - wn * G[1].to(gy.dtype)
+        return gx * g, gy * g, None, None, None, None

@@ -108,6 +108,57 @@ DI float comp(f2 a, int k) { return k == 0 ? a.x : a.y; }
 DI bool mcomp(bool m, int) { return m; }
 DI bool mcomp(i2 m, int k) { return (k == 0 ? m.x : m.y) != 0; }
 
+
+// ------------------------------------------------------------------------------------------------
+// Dual numbers for the tangent trace: a value and K directional derivatives.  Instantiating the
+// visit templates with T = Dual<K> differentiates exactly the formulas the plain trace evaluates,
+// branch for branch (the masks are taken on the values), which is what autograd does to the
+// reference's torch ops (torch.where routes gradients by the mask, relu'/abs' follow the sign).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+struct Dual {
+  float v;
+  float t[K];
+  DI Dual() {}
+  DI Dual(float x) : v(x) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = 0.0f;
+  }
+};
+template <int K> struct LaneOf<Dual<K>> { using M = bool; static constexpr int N = 1; };
+
+#define RTT_DUAL_LOOP _Pragma("unroll") for (int k = 0; k < K; ++k)
+template <int K> DI Dual<K> operator+(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v + b.v; RTT_DUAL_LOOP r.t[k] = a.t[k] + b.t[k]; return r; }
+template <int K> DI Dual<K> operator-(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v - b.v; RTT_DUAL_LOOP r.t[k] = a.t[k] - b.t[k]; return r; }
+template <int K> DI Dual<K> operator*(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v * b.v; RTT_DUAL_LOOP r.t[k] = a.t[k] * b.v + a.v * b.t[k]; return r; }
+template <int K> DI Dual<K> operator-(Dual<K> a) { Dual<K> r; r.v = -a.v; RTT_DUAL_LOOP r.t[k] = -a.t[k]; return r; }
+template <int K> DI Dual<K> operator+(Dual<K> a, float b) { a.v += b; return a; }
+template <int K> DI Dual<K> operator+(float a, Dual<K> b) { b.v += a; return b; }
+template <int K> DI Dual<K> operator-(Dual<K> a, float b) { a.v -= b; return a; }
+template <int K> DI Dual<K> operator-(float a, Dual<K> b) { return (-b) + a; }
+template <int K> DI Dual<K> operator*(Dual<K> a, float b) { a.v *= b; RTT_DUAL_LOOP a.t[k] *= b; return a; }
+template <int K> DI Dual<K> operator*(float a, Dual<K> b) { return b * a; }
+template <int K> DI bool lt(Dual<K> a, Dual<K> b) { return a.v < b.v; }
+template <int K> DI bool le(Dual<K> a, Dual<K> b) { return a.v <= b.v; }
+template <int K> DI bool ge(Dual<K> a, Dual<K> b) { return a.v >= b.v; }
+template <int K> DI bool gt(Dual<K> a, Dual<K> b) { return a.v > b.v; }
+template <int K> DI bool isnan_(Dual<K> a) { return a.v != a.v; }
+template <int K> DI Dual<K> sel(bool m, Dual<K> a, Dual<K> b) { return m ? a : b; }
+template <int K> DI Dual<K> abs_(Dual<K> a) { return a.v < 0.0f ? -a : (a.v > 0.0f ? a : Dual<K>(fabsf(a.v))); }
+template <int K> DI Dual<K> max_(Dual<K> a, Dual<K> b) { return (a.v > b.v || b.v != b.v) ? a : b; }
+template <int K> DI Dual<K> min_(Dual<K> a, Dual<K> b) { return (a.v < b.v || b.v != b.v) ? a : b; }
+// f(a) with derivative fp: chain rule on every tangent
+template <int K> DI Dual<K> chain(Dual<K> a, float f, float fp) { Dual<K> r; r.v = f; RTT_DUAL_LOOP r.t[k] = fp * a.t[k]; return r; }
+template <int K> DI Dual<K> rcp_(Dual<K> a) { const float r = rcp_(a.v); return chain(a, r, -r * r); }
+template <int K> DI Dual<K> sqrt_(Dual<K> a) { const float s = sqrt_(a.v); return chain(a, s, 0.5f * rcp_(s)); }
+template <int K> DI Dual<K> sqrt_disc(Dual<K> a) { const float s = sqrt_disc(a.v); return chain(a, s, 0.5f * rcp_(s)); }
+template <int K> DI Dual<K> sqrt_ieee(Dual<K> a) { const float s = sqrtf(a.v); return chain(a, s, 0.5f / s); }
+template <int K> DI Dual<K> rsq_(Dual<K> a) { const float r = rsq_(a.v); return chain(a, r, -0.5f * r * r * r); }
+template <int K> DI Dual<K> quot(Dual<K> a, Dual<K> b) { return a * rcp_(b); }
+template <int K> DI Dual<K> div_ieee(Dual<K> a, Dual<K> b) { return a * rcp_(b); }
+template <int K> DI float comp(Dual<K> a, int) { return a.v; }
+#undef RTT_DUAL_LOOP
+
 template <class T>
 struct V3 {
   T x, y, z;
@@ -183,21 +234,68 @@ __device__ __forceinline__ int op_of(const Ops& ops, int s) { return (ops.w[s >>
     default: CALL(CGeneric); break;                    \
   }
 
-// v @ R, R row-major (geom/transform.py:92-93).  `ident` skips the products: with R exactly the
-// identity x*1 + y*0 + z*0 == x bit for bit for finite inputs.
-template <class T>
-DI V3<T> rowmat(V3<T> v, const float* R, bool ident) {
+// Record views.  The arithmetic reads record fields through a view so that the same templates serve the
+// plain trace (fields are wave-uniform floats in scalar registers) and the tangent trace (fields are
+// dual numbers carrying d(field)/d(parameter)).
+struct RecF {
+  const RttSurface& r;
+  DI float Rs(int i) const { return r.Rs[i]; }
+  DI float ts(int i) const { return r.ts[i]; }
+  DI float Rj(int i) const { return r.Rj[i]; }
+  DI float tj(int i) const { return r.tj[i]; }
+  DI float geom(int i) const { return r.geom[i]; }
+  DI float phys(int i) const { return r.phys[i]; }
+  DI float bnd(int i) const { return r.bnd[i]; }
+  DI float shp(int i) const { return r.shp[i]; }
+};
+
+// Tangent view of a record: the 32 differentiable slots (Rs 0-8, ts 9-11, Rj 12-20, tj 21-23, geom 24-27,
+// phys 28-31) carry d(slot)/d(theta_k) from a per-surface table [32][K]; bounds are not differentiated
+// (masks are piecewise constant).
+constexpr int kTanSlots = 32;
+template <int K>
+struct RecD {
+  const RttSurface& r;
+  const float* tan;  // [kTanSlots][K] of this surface
+  DI Dual<K> mk(float v, int slot) const {
+    Dual<K> d;
+    d.v = v;
+#pragma unroll
+    for (int k = 0; k < K; ++k) d.t[k] = tan[slot * K + k];
+    return d;
+  }
+  DI Dual<K> Rs(int i) const { return mk(r.Rs[i], i); }
+  DI Dual<K> ts(int i) const { return mk(r.ts[i], 9 + i); }
+  DI Dual<K> Rj(int i) const { return mk(r.Rj[i], 12 + i); }
+  DI Dual<K> tj(int i) const { return mk(r.tj[i], 21 + i); }
+  DI Dual<K> geom(int i) const { return mk(r.geom[i], 24 + i); }
+  DI Dual<K> phys(int i) const { return mk(r.phys[i], 28 + i); }
+  DI float bnd(int i) const { return r.bnd[i]; }
+  DI float shp(int i) const { return r.shp[i]; }
+};
+
+// v @ R, R row-major (geom/transform.py:92-93); W = 0 takes the element rotation Rs, W = 1 the surface
+// rotation Rj.  `ident` skips the products: with R exactly the identity x*1 + y*0 + z*0 == x bit for bit.
+template <int W, class RV>
+DI auto rot(const RV& S, int i) -> decltype(S.Rs(0)) {
+  return W == 0 ? S.Rs(i) : S.Rj(i);
+}
+
+template <int W, class T, class RV>
+DI V3<T> rowmat(V3<T> v, const RV& S, bool ident) {
   if (ident) return v;
-  return {v.x * R[0] + v.y * R[3] + v.z * R[6], v.x * R[1] + v.y * R[4] + v.z * R[7],
-          v.x * R[2] + v.y * R[5] + v.z * R[8]};
+  return {v.x * rot<W>(S, 0) + v.y * rot<W>(S, 3) + v.z * rot<W>(S, 6),
+          v.x * rot<W>(S, 1) + v.y * rot<W>(S, 4) + v.z * rot<W>(S, 7),
+          v.x * rot<W>(S, 2) + v.y * rot<W>(S, 5) + v.z * rot<W>(S, 8)};
 }
 
 // v @ R^T (geom/primitives.py:94, geom/shape.py:85)
-template <class T>
-DI V3<T> rowmat_t(V3<T> v, const float* R, bool ident) {
+template <int W, class T, class RV>
+DI V3<T> rowmat_t(V3<T> v, const RV& S, bool ident) {
   if (ident) return v;
-  return {v.x * R[0] + v.y * R[1] + v.z * R[2], v.x * R[3] + v.y * R[4] + v.z * R[5],
-          v.x * R[6] + v.y * R[7] + v.z * R[8]};
+  return {v.x * rot<W>(S, 0) + v.y * rot<W>(S, 1) + v.z * rot<W>(S, 2),
+          v.x * rot<W>(S, 3) + v.y * rot<W>(S, 4) + v.z * rot<W>(S, 5),
+          v.x * rot<W>(S, 6) + v.y * rot<W>(S, 7) + v.z * rot<W>(S, 8)};
 }
 
 // torch.min over a stacked dim propagates NaN (geom/primitives.py:34, geom/bounded.py:34)
@@ -214,15 +312,15 @@ struct Frames {
 
 // Global -> element frame (+ re-normalisation, rays/ray.py:22-25 via with_coords :84-97)
 // -> surface frame (geom/shape.py:37-38, geom/primitives.py:50, geom/transform.py:90-93).
-template <class C, class T>
-DI Frames<T> to_frames(const RttSurface& S, V3<T> p, V3<T> d) {
+template <class C, class RV, class T>
+DI Frames<T> to_frames(const RV& S, V3<T> p, V3<T> d) {
   Frames<T> f;
   V3<T> den;
-  if (C::has_shape(S)) {
-    const bool id = C::rs_id(S);
-    V3<T> ts = {splat<T>(S.ts[0]), splat<T>(S.ts[1]), splat<T>(S.ts[2])};
-    f.pe = rowmat(p - ts, S.Rs, id);
-    f.de = rowmat(d, S.Rs, id);
+  if (C::has_shape(S.r)) {
+    const bool id = C::rs_id(S.r);
+    V3<T> ts = {T(S.ts(0)), T(S.ts(1)), T(S.ts(2))};
+    f.pe = rowmat<0>(p - ts, S, id);
+    f.de = rowmat<0>(d, S, id);
     const T n2 = f.de.x * f.de.x + f.de.y * f.de.y + f.de.z * f.de.z;
     if (kStrict) {
       const T n = max_(sqrt_ieee(n2), splat<T>(1e-12f));
@@ -236,10 +334,10 @@ DI Frames<T> to_frames(const RttSurface& S, V3<T> p, V3<T> d) {
     f.de = d;
     den = d;
   }
-  const bool idj = C::rj_id(S);
-  V3<T> tj = {splat<T>(S.tj[0]), splat<T>(S.tj[1]), splat<T>(S.tj[2])};
-  f.pl = rowmat(f.pe - tj, S.Rj, idj);
-  f.dl = rowmat(den, S.Rj, idj);
+  const bool idj = C::rj_id(S.r);
+  V3<T> tj = {T(S.tj(0)), T(S.tj(1)), T(S.tj(2))};
+  f.pl = rowmat<1>(f.pe - tj, S, idj);
+  f.dl = rowmat<1>(den, S, idj);
   return f;
 }
 
@@ -277,10 +375,10 @@ DI void quadratic_with_linear_fallback(T A, T B, T Cc, T& t1, T& t2, M& ok) {
 
 // _solve_t of each primitive in the surface frame.  Returns the number of roots (1 or 2); `ok`
 // false marks roots the reference sets to inf.
-template <class C, class T, class M>
-DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
+template <class C, class RV, class T, class M>
+DI int solve_roots(const RV& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
   const T zero = splat<T>(0.0f);
-  switch (C::sk(S)) {
+  switch (C::sk(S.r)) {
     case RTT_SURF_PLANE: {  // geom/primitives.py:124-136
       const T safe = sel(lt(abs_(d.z), splat<T>(kEps)), splat<T>(1e-8f), d.z);
       t1 = quot(-o.z, safe);
@@ -290,7 +388,7 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
     }
     case RTT_SURF_SPHERE: {  // geom/primitives.py:155-181
       const T b = 2.0f * dot3(o, d);
-      const T c = dot3(o, o) - S.geom[1];
+      const T c = dot3(o, o) - S.geom(1);
       const T disc = b * b - 4.0f * c;
       ok = ge(disc, zero);
       const T sq = sqrt_disc(sel(ok, disc, zero));
@@ -301,7 +399,7 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
     case RTT_SURF_CYLINDER: {  // geom/primitives.py:201-231
       const T A = d.x * d.x + d.y * d.y;
       const T B = 2.0f * (o.x * d.x + o.y * d.y);
-      const T Cc = (o.x * o.x + o.y * o.y) - S.geom[1];
+      const T Cc = (o.x * o.x + o.y * o.y) - S.geom(1);
       const T disc = B * B - 4.0f * A * Cc;
       ok = ge(disc, zero);
       const T sq = sqrt_disc(abs_(disc));
@@ -312,8 +410,8 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
       return 2;
     }
     case RTT_SURF_QUADRIC: {  // geom/primitives.py:266-288
-      const float c = S.geom[0], c1k = S.geom[2];
-      const float two_c = 2.0f * c, two_c1k = 2.0f * c1k;
+      const auto c = S.geom(0), c1k = S.geom(2);
+      const auto two_c = 2.0f * c, two_c1k = 2.0f * c1k;
       const T A = c * (d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
       const T B = two_c * (o.x * d.x + o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
       const T Cc = c * (o.x * o.x + o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
@@ -321,8 +419,8 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
       return 2;
     }
     case RTT_SURF_QUADRIC_ZY: {  // geom/primitives.py:356-377
-      const float c = S.geom[0], c1k = S.geom[2];
-      const float two_c = 2.0f * c, two_c1k = 2.0f * c1k;
+      const auto c = S.geom(0), c1k = S.geom(2);
+      const auto two_c = 2.0f * c, two_c1k = 2.0f * c1k;
       const T A = c * (d.y * d.y) + c1k * (d.z * d.z);
       const T B = two_c * (o.y * d.y) + two_c1k * o.z * d.z - 2.0f * d.z;
       const T Cc = c * (o.y * o.y) + c1k * (o.z * o.z) - 2.0f * o.z;
@@ -330,7 +428,7 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
       return 2;
     }
     default: {  // RTT_SURF_CONE, geom/primitives.py:416-466
-      const float k2 = S.geom[1];
+      const auto k2 = S.geom(1);
       const T A = d.z * d.z - k2 * (d.x * d.x + d.y * d.y);
       const T B = 2.0f * (o.z * d.z - k2 * (o.x * d.x + o.y * d.y));
       const T Cc = o.z * o.z - k2 * (o.x * o.x + o.y * o.y);
@@ -341,26 +439,26 @@ DI int solve_roots(const RttSurface& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
 }
 
 // SurfaceBounded.inBounds variants in the surface frame, without `invert` (geom/bounded.py).
-template <class C, class T>
-DI typename LaneOf<T>::M surface_in_bounds(const RttSurface& S, V3<T> h) {
-  switch (C::bk(S)) {
+template <class C, class RV, class T>
+DI typename LaneOf<T>::M surface_in_bounds(const RV& S, V3<T> h) {
+  switch (C::bk(S.r)) {
     case RTT_BND_DISK:  // bounded.py:60-64
-      return le(h.x * h.x + h.y * h.y, splat<T>(S.bnd[0]));
+      return le(h.x * h.x + h.y * h.y, splat<T>(S.bnd(0)));
     case RTT_BND_RECT:  // bounded.py:77-82
-      return and_(le(abs_(h.x), splat<T>(S.bnd[0])), le(abs_(h.y), splat<T>(S.bnd[1])));
+      return and_(le(abs_(h.x), splat<T>(S.bnd(0))), le(abs_(h.y), splat<T>(S.bnd(1))));
     case RTT_BND_ELLIPSE: {  // bounded.py:98-106
-      const T dM = h.x * S.bnd[0] - h.y * S.bnd[1];
-      const T dm = h.x * S.bnd[1] + h.y * S.bnd[0];
-      const T a = quot(dM, splat<T>(S.bnd[2]));
-      const T b = quot(dm, splat<T>(S.bnd[3]));
+      const T dM = h.x * S.bnd(0) - h.y * S.bnd(1);
+      const T dm = h.x * S.bnd(1) + h.y * S.bnd(0);
+      const T a = quot(dM, splat<T>(S.bnd(2)));
+      const T b = quot(dm, splat<T>(S.bnd(3)));
       return le(a * a + b * b, splat<T>(1.0f));
     }
     case RTT_BND_HALF:  // bounded.py:123-127, :171-174
-      return lt(abs_(h.z * S.geom[0]), splat<T>(1.000001f));
+      return lt(abs_(h.z * S.geom(0)), splat<T>(1.000001f));
     case RTT_BND_HALF_DISK:  // bounded.py:151-159
-      return and_(lt(abs_(h.z * S.geom[0]), splat<T>(1.000001f)), le(h.x * h.x + h.y * h.y, splat<T>(S.bnd[0])));
+      return and_(lt(abs_(h.z * S.geom(0)), splat<T>(1.000001f)), le(h.x * h.x + h.y * h.y, splat<T>(S.bnd(0))));
     case RTT_BND_SINGLE_CONE:  // bounded.py:208-217
-      return ge(h.z * S.geom[0], splat<T>(-kEps));
+      return ge(h.z * S.geom(0), splat<T>(-kEps));
     default:  // RTT_BND_ALWAYS
       return ge(splat<T>(1.0f), splat<T>(0.0f));
   }
@@ -369,20 +467,20 @@ DI typename LaneOf<T>::M surface_in_bounds(const RttSurface& S, V3<T> h) {
 // Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36).
 // `ok` false stands for a root the reference has already replaced by inf: inf fails neither the
 // epsilon test nor (as a NaN hit point) an un-inverted bound, so it stays inf there as here.
-template <class C, class T, class M>
-DI T filter_root(const RttSurface& S, const Frames<T>& f, T r, M ok) {
+template <class C, class RV, class T, class M>
+DI T filter_root(const RV& S, const Frames<T>& f, T r, M ok) {
   auto bad = or_(not_(ok), le(r, splat<T>(kEps)));
-  if (C::bk(S) != RTT_BND_NONE) {
+  if (C::bk(S.r) != RTT_BND_NONE) {
     V3<T> h = f.pl + scale(r, f.dl);
     auto keep = surface_in_bounds<C>(S, h);
-    if (S.flags & RTT_F_INVERT) keep = not_(keep);
+    if (S.r.flags & RTT_F_INVERT) keep = not_(keep);
     bad = or_(bad, not_(keep));
   }
   return sel(bad, splat<T>(kInf), r);
 }
 
-template <class C, class T>
-DI T solve_t(const RttSurface& S, const Frames<T>& f) {
+template <class C, class RV, class T>
+DI T solve_t(const RV& S, const Frames<T>& f) {
   T t1, t2;
   typename LaneOf<T>::M ok;
   const int n = solve_roots<C>(S, f.pl, f.dl, t1, t2, ok);
@@ -390,7 +488,7 @@ DI T solve_t(const RttSurface& S, const Frames<T>& f) {
   if (n == 1) return t1;
   t2 = filter_root<C>(S, f, t2, ok);
   // a NaN root survives only on unbounded surfaces or inverted bounds (a NaN hit point is out of bounds)
-  if (C::bk(S) != RTT_BND_NONE && !(S.flags & RTT_F_INVERT)) return min_(t1, t2);
+  if (C::bk(S.r) != RTT_BND_NONE && !(S.r.flags & RTT_F_INVERT)) return min_(t1, t2);
   return nanmin(t1, t2);
 }
 
@@ -405,20 +503,20 @@ DI T sag(float c, float tz, T y) {
 }
 
 // Shape.inBounds(hit, j) in the element frame (geom/spherics.py:27-46, geom/cylindrics.py:23-55)
-template <class C, class T>
-DI typename LaneOf<T>::M shape_in_bounds(const RttSurface& S, V3<T> h) {
-  switch (C::hk(S)) {
+template <class C, class RV, class T>
+DI typename LaneOf<T>::M shape_in_bounds(const RV& S, V3<T> h) {
+  switch (C::hk(S.r)) {
     case RTT_SHP_SPHERIC_FACE:
-      return le(h.x * h.x + h.y * h.y, splat<T>(S.shp[0]));
+      return le(h.x * h.x + h.y * h.y, splat<T>(S.shp(0)));
     case RTT_SHP_SPHERIC_EDGE:
-      return and_(ge(h.z, splat<T>(S.shp[0])), le(h.z, splat<T>(S.shp[1])));
+      return and_(ge(h.z, splat<T>(S.shp(0))), le(h.z, splat<T>(S.shp(1))));
     case RTT_SHP_CYL_FACE:
     case RTT_SHP_CYL_EDGE: {
-      const auto ap = and_(and_(le(h.x, splat<T>(S.shp[0])), ge(h.x, splat<T>(S.shp[1]))),
-                           and_(le(h.y, splat<T>(S.shp[2])), ge(h.y, splat<T>(S.shp[3]))));
-      if (C::hk(S) == RTT_SHP_CYL_FACE) return ap;
-      const T zf = sag(S.shp[4], S.shp[5], h.y);
-      const T zb = sag(S.shp[6], S.shp[7], h.y);
+      const auto ap = and_(and_(le(h.x, splat<T>(S.shp(0))), ge(h.x, splat<T>(S.shp(1)))),
+                           and_(le(h.y, splat<T>(S.shp(2))), ge(h.y, splat<T>(S.shp(3)))));
+      if (C::hk(S.r) == RTT_SHP_CYL_FACE) return ap;
+      const T zf = sag(S.shp(4), S.shp(5), h.y);
+      const T zb = sag(S.shp(6), S.shp(7), h.y);
       return and_(and_(ge(h.z, zf + 1e-4f), le(h.z, zb - 1e-4f)), ap);
     }
     default:
@@ -429,12 +527,12 @@ DI typename LaneOf<T>::M shape_in_bounds(const RttSurface& S, V3<T> h) {
 // One column of Element.intersectTest (geom/shape.py:42-56 or geom/primitives.py:38-57), returned as
 // the hit mask `t < inf` together with the frames and the un-masked t (what Shape.forward recomputes,
 // geom/shape.py:78).  masked_t() gives the column value itself.
-template <class C, class T>
-DI typename LaneOf<T>::M test_surface(const RttSurface& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
+template <class C, class RV, class T>
+DI typename LaneOf<T>::M test_surface(const RV& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
   f = to_frames<C>(S, p, d);
   t_raw = solve_t<C>(S, f);
   auto valid = lt(t_raw, splat<T>(kInf));
-  if (C::has_shape(S)) {
+  if (C::has_shape(S.r)) {
     V3<T> he = f.pe + scale(t_raw, f.de);
     valid = and_(valid, shape_in_bounds<C>(S, he));
   }
@@ -443,30 +541,30 @@ DI typename LaneOf<T>::M test_surface(const RttSurface& S, V3<T> p, V3<T> d, Fra
 
 // the [N, K] matrix entry: a Shape replaces every invalid t (NaN included) by inf, a bare Surface
 // returns its t as is (geom/shape.py:50-55 vs geom/primitives.py:55-57)
-template <class C, class T, class M>
-DI T masked_t(const RttSurface& S, T t_raw, M valid) {
-  return C::has_shape(S) ? sel(valid, t_raw, splat<T>(kInf)) : t_raw;
+template <class C, class RV, class T, class M>
+DI T masked_t(const RV& S, T t_raw, M valid) {
+  return C::has_shape(S.r) ? sel(valid, t_raw, splat<T>(kInf)) : t_raw;
 }
 
 // _getNormal in the surface frame
-template <class C, class T>
-DI V3<T> surface_normal(const RttSurface& S, V3<T> h) {
+template <class C, class RV, class T>
+DI V3<T> surface_normal(const RV& S, V3<T> h) {
   const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
-  switch (C::sk(S)) {
+  switch (C::sk(S.r)) {
     case RTT_SURF_PLANE:  // primitives.py:138-143
       return {zero, zero, one};
     case RTT_SURF_SPHERE: {  // primitives.py:183-187
-      const T R = splat<T>(S.geom[0]);
+      const T R = T(S.geom(0));
       return {quot(h.x, R), quot(h.y, R), quot(h.z, R)};
     }
     case RTT_SURF_CYLINDER: {  // primitives.py:233-241
-      const T R = splat<T>(S.geom[0]);
+      const T R = T(S.geom(0));
       return {quot(h.x, R), quot(h.y, R), zero};
     }
     case RTT_SURF_QUADRIC:
     case RTT_SURF_QUADRIC_ZY: {  // primitives.py:330-343, :379-395
-      const float two_c = 2.0f * S.geom[0], two_c1k = 2.0f * S.geom[2];
-      const T nx = C::sk(S) == RTT_SURF_QUADRIC ? two_c * h.x : zero;
+      const auto two_c = 2.0f * S.geom(0), two_c1k = 2.0f * S.geom(2);
+      const T nx = C::sk(S.r) == RTT_SURF_QUADRIC ? two_c * h.x : zero;
       const T ny = two_c * h.y;
       const T nz = two_c1k * h.z - 2.0f;
       const T len = sqrt_(nx * nx + ny * ny + nz * nz) + 1e-8f;
@@ -475,7 +573,7 @@ DI V3<T> surface_normal(const RttSurface& S, V3<T> h) {
       return {nx * r, ny * r, nz * r};
     }
     default: {  // cone, primitives.py:468-497
-      const float k2 = S.geom[1];
+      const auto k2 = S.geom(1);
       const T nx = -k2 * h.x, ny = -k2 * h.y, nz = h.z;
       const T len = sqrt_(nx * nx + ny * ny + nz * nz);
       const auto ok = gt(len, splat<T>(1e-8f));
@@ -491,23 +589,23 @@ struct Forward {
 };
 
 // Shape.forward / Surface.forward given frames and t (geom/shape.py:78-87, geom/primitives.py:85-96)
-template <class C, class T>
-DI Forward<T> surface_forward(const RttSurface& S, V3<T> p, V3<T> d, const Frames<T>& f, T t) {
+template <class C, class RV, class T>
+DI Forward<T> surface_forward(const RV& S, V3<T> p, V3<T> d, const Frames<T>& f, T t) {
   Forward<T> o;
   o.hit_g = p + scale(t, d);
   o.hit_l = f.pl + scale(t, f.dl);
   V3<T> n = surface_normal<C>(S, o.hit_l);
-  n = rowmat_t(n, S.Rj, C::rj_id(S));
-  if (C::has_shape(S)) n = rowmat_t(n, S.Rs, C::rs_id(S));
+  n = rowmat_t<1>(n, S, C::rj_id(S.r));
+  if (C::has_shape(S.r)) n = rowmat_t<0>(n, S, C::rs_id(S.r));
   o.n_g = n;
   return o;
 }
 
 // SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult)
-template <class C, class T>
-DI void apply_physics(const RttSurface& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im) {
+template <class C, class RV, class T>
+DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im) {
   const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
-  switch (C::pk(S)) {
+  switch (C::pk(S.r)) {
     case RTT_PHYS_BLOCK:  // phys/std.py:243-254
       nd = {zero, zero, zero};
       im = zero;
@@ -522,7 +620,7 @@ DI void apply_physics(const RttSurface& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd
       const T dot = dot3(d, n);
       const auto ent = lt(dot, zero);
       const T c1 = abs_(dot);
-      const T mu = sel(ent, splat<T>(S.phys[2]), splat<T>(S.phys[3]));
+      const T mu = sel(ent, T(S.phys(2)), T(S.phys(3)));
       const T term = 1.0f - mu * mu * (1.0f - c1 * c1);
       // sqrt(relu(term)); a NaN term comes with a NaN c1, so the result is NaN through g either way
       const T c2 = sqrt_(max_(term, zero));
@@ -636,16 +734,16 @@ DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, 
 
 // Apply surface S to the ray(s) of a lane where hit: Element.forward + Rays.scatter_update
 // (elements/parent.py:44-58, rays/ray.py:29-40, elements/sensor.py:35-37).
-template <class C, class T, class M>
-DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i,
+template <class C, class RV, class T, class M>
+DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i,
                  int nv = LaneOf<T>::N) {
-  const bool sensor = (S.flags & RTT_F_SENSOR) != 0;
+  const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
   if (!sensor && !any_(hit)) return;  // lanes without a hit are done; a wavefront without hits skips the block
   Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
   V3<T> nd;
   T im;
   apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im);
-  if (sensor) record_sensor(se, S.sensor_slot, i, hit, fw.hit_l, r.I, nv);
+  if (sensor) record_sensor(se, S.r.sensor_slot, i, hit, fw.hit_l, r.I, nv);
   if (__all(!any_(not_(hit)))) {  // every ray of the wavefront hits: plain moves, no selects
     r.p = fw.hit_g;
     r.d = nd;
@@ -658,8 +756,8 @@ DI void interact(const RttSurface& S, const Frames<T>& f, T t_raw, M hit, Ray<T>
 }
 
 // test + interact of one surface (scene/sequential.py:19-34)
-template <class C, class T>
-DI void visit_seq(const RttSurface& S, Ray<T>& r, const SensorIO& se, int64_t i, int nv) {
+template <class C, class RV, class T>
+DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, int64_t i, int nv) {
   Frames<T> f;
   T t_raw;
   const auto hit = test_surface<C>(S, r.p, r.d, f, t_raw);
@@ -684,12 +782,97 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
     const int nv = (io.n - i) >= N ? N : 1;
     Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
     for (int s = 0; s < n_surf; ++s) {
-      const RttSurface& S = prog[s];
+      const RecF S{prog[s]};
 #define RTT_CALL(CFG) visit_seq<CFG>(S, r, se, i, nv)
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     }
     store_ray<T>(io, i, r, vec != 0, nv);
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tangent of the sequential trace, contracted with upstream adjoints (backward of
+// SequentialScene.simulate for the parameters of the scene).  Each lane re-traces its ray with dual
+// numbers (K parameter directions at once) and accumulates
+//     dtheta[k] += sum_c adj_pos[c][i] * d pos_c / d theta_k + adj_dir[c][i] * d dir_c / d theta_k
+//                + sum over sensor surfaces the ray hits:  adj_sens[slot][c][i] * d hit_local_c / d theta_k
+// in float64 (wave shuffle -> LDS -> one atomicAdd per block and k).  Masks, root choice, TIR and
+// `entering` are piecewise constant and carry no derivative, as under autograd.
+// ------------------------------------------------------------------------------------------------
+struct TangentIO {
+  const float* tan;      // [n_surf][kTanSlots][K]
+  const float* adj_pos;  // [3][ld_adj] or null
+  const float* adj_dir;  // [3][ld_adj] or null
+  int64_t ld_adj;
+  const float* adj_sens;  // [slots][3][sens_ld] or null
+  int64_t sens_ld;
+  double* dtheta;  // [K]
+};
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
+                                                              TangentIO tio) {
+  using T = Dual<K>;
+  __shared__ double part[K][kBlock / 64];
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
+    Ray<float> r0 = load_ray<float>(io, i);
+    Ray<T> r;
+    r.p = {T(r0.p.x), T(r0.p.y), T(r0.p.z)};
+    r.d = {T(r0.d.x), T(r0.d.y), T(r0.d.z)};
+    r.I = T(r0.I);
+    for (int s = 0; s < n_surf; ++s) {
+      const RecD<K> S{prog[s], tio.tan + (int64_t)s * kTanSlots * K};
+      Frames<T> f;
+      T t_raw;
+      const bool hit = test_surface<CGeneric>(S, r.p, r.d, f, t_raw);
+      if (!hit) continue;
+      Forward<T> fw = surface_forward<CGeneric>(S, r.p, r.d, f, t_raw);
+      V3<T> nd;
+      T im;
+      apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im);
+      if ((S.r.flags & RTT_F_SENSOR) && tio.adj_sens) {
+        const float* a = tio.adj_sens + (int64_t)S.r.sensor_slot * 3 * tio.sens_ld + i;
+        const float ax = a[0], ay = a[tio.sens_ld], az = a[2 * tio.sens_ld];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          acc[k] += (double)(ax * fw.hit_l.x.t[k] + ay * fw.hit_l.y.t[k] + az * fw.hit_l.z.t[k]);
+      }
+      r.p = fw.hit_g;
+      r.d = nd;
+      r.I = r.I * im;
+    }
+    if (tio.adj_pos) {
+      const float ax = tio.adj_pos[i], ay = tio.adj_pos[tio.ld_adj + i], az = tio.adj_pos[2 * tio.ld_adj + i];
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += (double)(ax * r.p.x.t[k] + ay * r.p.y.t[k] + az * r.p.z.t[k]);
+    }
+    if (tio.adj_dir) {
+      const float ax = tio.adj_dir[i], ay = tio.adj_dir[tio.ld_adj + i], az = tio.adj_dir[2 * tio.ld_adj + i];
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += (double)(ax * r.d.x.t[k] + ay * r.d.y.t[k] + az * r.d.z.t[k]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) part[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double sum = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) sum += part[threadIdx.x][w];
+    atomicAdd(&tio.dtheta[threadIdx.x], sum);
   }
 }
 
@@ -702,7 +885,7 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops,
   tmin = kInf;
   win = 0;
   for (int s = 0; s < n_surf; ++s) {
-    const RttSurface& S = prog[s];
+    const RecF S{prog[s]};
     Frames<float> f;
     float t_raw = kInf, t = kInf;
 #define RTT_CALL(CFG)                                          \
@@ -755,7 +938,7 @@ __global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurf
     while (pending) {
       const int s = __builtin_amdgcn_readfirstlane(win);
       if (win == s) {
-        const RttSurface& S = prog[s];
+        const RecF S{prog[s]};
 #define RTT_CALL(CFG)                                  \
   {                                                    \
     Frames<float> f = to_frames<CFG>(S, r.p, r.d);     \
@@ -785,8 +968,9 @@ __global__ void __launch_bounds__(kBlock) k_intersect_test(const float* __restri
     for (int s = 0; s < n_surf; ++s) {
       Frames<float> f;
       float t_raw;
-      const bool valid = test_surface<CGeneric>(prog[s], p, d, f, t_raw);
-      t_out[(int64_t)s * ld_t + i] = masked_t<CGeneric>(prog[s], t_raw, valid);
+      const RecF S{prog[s]};
+      const bool valid = test_surface<CGeneric>(S, p, d, f, t_raw);
+      t_out[(int64_t)s * ld_t + i] = masked_t<CGeneric>(S, t_raw, valid);
     }
   }
 }
@@ -817,7 +1001,7 @@ __global__ void __launch_bounds__(kBlock) k_surface_forward(const float* __restr
                                                             const RttSurface* __restrict__ prog, int index,
                                                             ForwardOut o) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  const RttSurface& S = prog[index];
+  const RecF S{prog[index]};
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
     V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
@@ -843,7 +1027,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_physics(const float* __restric
                                                           const RttSurface* __restrict__ prog,
                                                           float* __restrict__ new_dir, float* __restrict__ imult) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  const RttSurface& S = prog[0];
+  const RecF S{prog[0]};
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     V3<float> h = {hl[i], hl[ld + i], hl[2 * ld + i]};
     V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
@@ -859,11 +1043,6 @@ __global__ void __launch_bounds__(kBlock) k_apply_physics(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // SpotSizeLoss moments (optim/goals.py:165-183)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
 __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ w,
                                                          const uint8_t* __restrict__ mask, int64_t n, int pass,
@@ -1018,6 +1197,31 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
     hipLaunchKernelGGL(k_trace_seq<float>, dim3(grid_for(n, 1)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, 0);
   else
     hipLaunchKernelGGL(k_trace_seq<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
+  return launch_status();
+}
+
+int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                              const float* tan_dev, int n_theta, const float* adj_pos, const float* adj_dir,
+                              int64_t ld_adj, const float* adj_sens, int64_t sens_ld, double* dtheta, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !prog_dev || !tan_dev || !dtheta) return RTT_E_NULL;
+  if (n < 0 || ld_in < n || (n_theta != 4 && n_theta != 8)) return RTT_E_SIZE;
+  if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
+  if (adj_sens && sens_ld < n) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(tan_dev) || misaligned(adj_pos) ||
+      misaligned(adj_dir) || misaligned(adj_sens) || (reinterpret_cast<uintptr_t>(dtheta) & 7u))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
+  TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta};
+  const hipStream_t st = (hipStream_t)stream;
+  if (n_theta == 4)
+    hipLaunchKernelGGL(k_trace_seq_tangent<4>, dim3(grid_for(n)), dim3(kBlock), 0, st, io, prog_dev, n_surf, tio);
+  else
+    hipLaunchKernelGGL(k_trace_seq_tangent<8>, dim3(grid_for(n)), dim3(kBlock), 0, st, io, prog_dev, n_surf, tio);
   return launch_status();
 }
 

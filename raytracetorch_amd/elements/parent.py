@@ -29,6 +29,11 @@ class Element(nn.Module):
     def _program(self):
         return np.stack([self._record(j) for j in range(len(self.shape))])
 
+    def _diff_slots(self, j: int):
+        d = self.shape._diff_slots(j)
+        d["phys"] = self.surface_functions[j]._diff_phys()
+        return d
+
     # ---- reference API ------------------------------------------------------------------------
     def intersectTest(self, rays):
         return K.intersect_test(rays, self._program())

@@ -55,13 +55,34 @@ class Surface(nn.Module):
         rec["flags"] |= P.F_SHAPE_ROT_ID
         return rec
 
+    # ---- differentiable slots (torch expressions of the Parameters, used for gradients only) ----
+    def _diff_geom(self):
+        return None
+
+    def _diff_slots_surface(self):
+        return {"Rj": self.transform.rot, "tj": self.transform.trans, "geom": self._diff_geom()}
+
+    def _diff_slots(self, j: int):
+        return self._diff_slots_surface()
+
     # ---- reference API ------------------------------------------------------------------------
     def intersectTest(self, rays):
         return K.intersect_test(rays, self._surface_record()[None])
 
     def forward(self, rays, *args):
-        o = K.surface_forward(rays, self._surface_record()[None], 0, want_phys=False)
-        return o["t"], o["hit_global"], o["normal_global"], o["hit_local"]
+        """(t, hit_global, normal_global, hit_local).  When a parameter of this surface requires grad,
+        `hit_global` is differentiable with respect to it (the other outputs are returned detached)."""
+        rec = self._surface_record()
+        o = K.surface_forward(rays, rec[None], 0, want_phys=False)
+        hit_global = o["hit_global"]
+        from .. import autograd as AG
+        if AG.needs_grad([self]):
+            # hit_global = position after a sequential "trace" of this one surface with Transmit physics
+            rec["phys_kind"] = P.PHYS_TRANSMIT
+            outs = AG.trace_sequential_with_grad([_AsElement(self)], rays, rec[None])
+            moved = outs[0].t()
+            hit_global = torch.where((o["t"] < float("inf"))[:, None], moved, hit_global)
+        return o["t"], hit_global, o["normal_global"], o["hit_local"]
 
     @property
     def z(self):
@@ -73,6 +94,24 @@ class Surface(nn.Module):
     @property
     def surfaces(self):
         return (self,)
+
+
+class _AsElement:
+    """Adapter: lets a bare Surface stand where the gradient code expects an element."""
+
+    def __init__(self, surface):
+        self.shape = surface
+
+    def parameters(self):
+        return self.shape.parameters()
+
+    def modules(self):
+        return self.shape.modules()
+
+    def _diff_slots(self, j):
+        d = self.shape._diff_slots(j)
+        d["phys"] = None
+        return d
 
 
 class Plane(Surface):
@@ -95,6 +134,10 @@ class Sphere(Surface):
         r = P.scalar(self.radius)
         rec["geom"][:2] = (r, r * r)
 
+    def _diff_geom(self):
+        z = torch.zeros_like(self.radius)
+        return torch.stack([self.radius, self.radius * self.radius, z, z])
+
 
 class Cylinder(Surface):
     """x^2 + y^2 = R^2 along local z (geom/primitives.py:190-241)."""
@@ -107,6 +150,10 @@ class Cylinder(Surface):
     def _fill_geometry(self, rec):
         r = P.scalar(self.radius)
         rec["geom"][:2] = (r, r * r)
+
+    def _diff_geom(self):
+        z = torch.zeros_like(self.radius)
+        return torch.stack([self.radius, self.radius * self.radius, z, z])
 
 
 class Quadric(Surface):
@@ -122,6 +169,9 @@ class Quadric(Surface):
     def _fill_geometry(self, rec):
         c, k = P.scalar(self.c), P.scalar(self.k)
         rec["geom"][:3] = (c, k, c * (P.f32(1) + k))
+
+    def _diff_geom(self):
+        return torch.stack([self.c, self.k, self.c * (1 + self.k), torch.zeros_like(self.c)])
 
 
 class QuadricZY(Quadric):
@@ -140,3 +190,7 @@ class Cone(Surface):
     def _fill_geometry(self, rec):
         s = P.scalar(self.slope)
         rec["geom"][:2] = (s, s * s)
+
+    def _diff_geom(self):
+        z = torch.zeros_like(self.slope)
+        return torch.stack([self.slope, self.slope * self.slope, z, z])

@@ -34,6 +34,11 @@ class Shape(nn.Module):
         self._fill_shape_bound(rec, j)
         return rec
 
+    def _diff_slots(self, j: int):
+        d = self.surfaces[j]._diff_slots_surface()
+        d["Rs"], d["ts"] = self.transform.rot, self.transform.trans
+        return d
+
     def _program(self):
         import numpy as np
         return np.stack([self._record(j) for j in range(len(self.surfaces))])

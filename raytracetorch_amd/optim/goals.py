@@ -20,28 +20,20 @@ class Goal(nn.Module):
     pass
 
 
-def spot_size_from_records(records, target_xy=None):
+def spot_size_from_records(records, target_xy=None, group=None):
     """records: iterable of (x [M], y [M], w [M], mask [M] uint8 or None) device tensors.
-    Returns (loss tensor [] float64 on the device, moments tensor [4]) or (None, None) when no
-    record holds a hit with w > 0."""
+    Returns the loss tensor [] (differentiable w.r.t. x and y) or None when no record holds an entry."""
+    from ..autograd import SpotLossFn
     records = [r for r in records if r[0].numel() > 0]
     if not records:
-        return None, None
-    dev = records[0][0].device
-    mom = torch.zeros(4, device=dev, dtype=torch.float64)
-    for x, y, w, m in records:
-        K.spot_moments(x, y, w, m, 0, 0.0, 0.0, 1.0, mom)
-    W, Sx, Sy, _ = mom.tolist()
-    if W <= 0.0:
-        return None, None
-    W = max(W, 1e-12)
-    if target_xy is None:
-        cx, cy = Sx / W, Sy / W
+        return None
+    if len(records) == 1:
+        x, y, w, m = records[0]
     else:
-        cx, cy = float(target_xy[0]), float(target_xy[1])
-    for x, y, w, m in records:
-        K.spot_moments(x, y, w, m, 1, cx, cy, W, mom)
-    return mom[3], mom
+        ones = lambda r: torch.ones(r[0].numel(), dtype=torch.uint8, device=r[0].device) if r[3] is None else r[3]
+        x, y, w = (torch.cat([r[i] for r in records]) for i in range(3))
+        m = torch.cat([ones(r) for r in records])
+    return SpotLossFn.apply(x, y, w, m, target_xy, group)
 
 
 class SpotSizeLoss(Goal):
@@ -87,9 +79,11 @@ class SpotSizeLoss(Goal):
             tgt = None
             if self._target_xy is not None:
                 tgt = self._target_xy[min(i, self._target_xy.shape[0] - 1)]
-            loss, _ = spot_size_from_records(recs, tgt)
+            if not bool(torch.stack([((r[2] > 0) if r[3] is None else ((r[2] > 0) & r[3].bool())).any() for r in recs]).any()):
+                continue  # nothing lit reached the sensor (optim/goals.py:165-167)
+            loss = spot_size_from_records(recs, tgt, group=getattr(scene, "grad_group", None))
             if loss is not None:
                 losses.append(loss)
         if not losses:
             return torch.tensor(0.0)
-        return torch.stack(losses).mean().to(torch.float32)
+        return torch.stack(losses).mean()

@@ -21,6 +21,9 @@ class SurfaceFunction(nn.Module):
             raise NotImplementedError(f"{type(self).__name__} has no kernel description")
         rec["phys_kind"] = self._phys_kind
 
+    def _diff_phys(self):
+        return None
+
     def forward(self, local_intersect, ray_dir, normal, **kwargs):
         rec = P.new_record()
         self._fill_physics(rec)
@@ -58,3 +61,7 @@ class RefractSnell(SurfaceFunction):
         rec["phys_kind"] = self._phys_kind
         n_in, n_out = P.scalar(self.ior_in), P.scalar(self.ior_out)
         rec["phys"][:] = (n_in, n_out, n_out / n_in, n_in / n_out)
+
+    def _diff_phys(self):
+        a, b = self.ior_in, self.ior_out
+        return torch.stack([a, b, b / a, a / b])

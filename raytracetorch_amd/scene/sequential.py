@@ -22,6 +22,18 @@ class SequentialScene(Scene):
         (scene/sequential.py:12-36).  With `out` (a second Rays of the same size) the result goes
         there and `rays` is left untouched."""
         prog = self._program()
+        from .. import autograd as AG
+        if AG.needs_grad(self.elements):
+            # differentiable w.r.t. the scene parameters: the backward re-traces the (saved) input bundle
+            saved = rays.clone()
+            pos, d, inten, sens_hit, sens_w, sens_mask = AG.trace_sequential_with_grad(
+                list(self.elements), saved, prog, group=getattr(self, "grad_group", None))
+            dst = rays if out is None else out
+            dst._pos, dst._dir, dst.intensity = pos, d, inten
+            if sens_hit.numel() == 0:
+                sens_hit = sens_w = sens_mask = None
+            self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask)
+            return dst
         sens_hit, sens_w, sens_mask = K.trace_sequential(rays, prog, out=out)
         self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask)
         return rays if out is None else out

@@ -1,0 +1,138 @@
+"""GPU: gradients of the device trace w.r.t. scene parameters against the reference's autograd results
+(golden vectors) and against finite differences of the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+import rtt_oracle as O
+import scenes
+from util import golden
+
+import raytracetorch_amd.program as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GRAD_TOL = 1e-4  # relative, float32 tangents summed over 5e4 rays vs the reference's float32 autograd
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(1e-12, abs(float(b)))
+
+
+def test_reference_gradient_known_answers(ns):
+    """tests/test_primitive.py:166-307 of the reference: d(sum hit)/d(translation)."""
+    g = golden("grad_kats")
+    tr = torch.tensor([0.0, 0.0, 5.0], requires_grad=True)
+    plane = ns.Plane(transform=ns.RayTransform(translation=tr, trans_grad=True, rot_grad=False))
+    d = torch.tensor([[0.0, 1.0, 1.0]]); d = d / d.norm(dim=1, keepdim=True)
+    rays = ns.Rays.initialize(torch.tensor([[0.0, 0.0, 0.0]]), d).to(DEV)
+    _, hit, _, _ = plane(rays)
+    assert torch.allclose(hit.cpu(), torch.from_numpy(g["plane_hit"]), atol=1e-5)
+    hit.sum().backward()
+    assert np.allclose(plane.transform.trans.grad.numpy(), [0.0, 0.0, 2.0], atol=1e-5)
+    assert np.allclose(plane.transform.trans.grad.numpy(), g["plane_grad"], atol=1e-5)
+
+    tr = torch.tensor([0.0, 0.0, 5.0], requires_grad=True)
+    quad = ns.Quadric(transform=ns.RayTransform(translation=tr, trans_grad=True, rot_grad=False), c=0.01, k=0.0, c_grad=True)
+    rays = ns.Rays.initialize(torch.tensor([[5.0, 0.0, 0.0]]), torch.tensor([[0.0, 0.0, 1.0]])).to(DEV)
+    _, hit, _, _ = quad(rays)
+    hit.sum().backward()
+    assert np.allclose(quad.transform.trans.grad.numpy(), g["quadric_grad"], atol=1e-4)
+    assert abs(float(quad.transform.trans.grad[2]) - 1.0) < 1e-5
+    assert rel(quad.c.grad, g["quadric_grad_c"]) < 1e-4
+
+
+def test_spot_size_loss_gradients_match_reference(ns):
+    g = golden("spot_f32")
+    g64 = golden("spot_f64")
+    torch.manual_seed(0)
+    lens, sensor = scenes.spot_system(ns, grads=True)
+    loss_fn = ns.SpotSizeLoss(sensor, [scenes.disk_bundle(ns)], N_rays=65536)
+    scene = ns.SequentialScene([lens, sensor])
+    loss = loss_fn(scene)
+    assert rel(loss, g["loss"]) < 1e-5
+    loss.backward()
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    got = dict(c1=s0.c.grad, c2=s1.c.grad, t0=s0.transform.trans.grad[2], t1=s1.transform.trans.grad[2],
+               ior=lens.ior_glass.grad)
+    want = dict(c1=g["g_c1"], c2=g["g_c2"], t0=g["g_trans0"][2], t1=g["g_trans1"][2], ior=g["g_ior_glass"])
+    truth = dict(c1=g64["g_c1"], c2=g64["g_c2"], t0=g64["g_trans0"][2], t1=g64["g_trans1"][2], ior=g64["g_ior_glass"])
+    for k in got:
+        # within 1e-4 of the reference's float32 gradient, or closer to its float64 gradient than the
+        # float32 reference is (the two float32 evaluations differ by summation order)
+        ok = rel(got[k], want[k]) < GRAD_TOL or rel(got[k], truth[k]) <= 1.5 * rel(want[k], truth[k])
+        assert ok, (k, float(got[k]), float(want[k]), float(truth[k]))
+    # masked translation components stay zero (geom/transform.py:29-35)
+    assert float(s0.transform.trans.grad[0]) == 0.0 and float(s0.transform.trans.grad[1]) == 0.0
+
+
+def test_trace_gradients_vs_oracle_finite_differences(ns):
+    """d(sum of a random projection of the output rays)/d(theta) for a posed lens with rotation, conic
+    constant and both indices trainable, against central differences of the float64 oracle."""
+    torch.manual_seed(1)
+    mk = lambda: ns.SingletLens(c1=0.05, c2=-0.04, d=10.0, t=3.0, ior_glass=1.5, ior_media=1.0, inked=True,
+                                c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True, ior_media_grad=True,
+                                transform=ns.RayTransform(translation=[0.2, -0.1, 1.0], rotation=[0.03, -0.02, 0.1],
+                                                          trans_grad=True, rot_grad=True))
+    lens = mk()
+    rays0 = scenes.disk_bundle(ns, radius=3.5, rot=[0.02, 0.01, 0.0]).sample(2048)
+    wp, wd = torch.randn(3, 2048), torch.randn(3, 2048)
+    r = ns.SequentialScene([lens]).simulate(rays0.to(DEV))
+    obj = (r._pos * wp.to(DEV)).sum() + (r._dir * wd.to(DEV)).sum()
+    obj.backward()
+
+    def oracle_obj(lens_):
+        prog = P.compile_elements([lens_])
+        # float64 evaluation of the packed (float32-rounded) parameters is too coarse for differences;
+        # perturb in float64 directly on the records instead
+        return prog
+
+    def objective(prog):
+        o = O.trace_sequential(prog, rays0.pos, rays0.dir, rays0.intensity, dtype=torch.float64)
+        return float((o["pos"].t() * wp.double()).sum() + (o["dir"].t() * wd.double()).sum())
+
+    base = P.compile_elements([lens]).copy()
+    # c1 of surface 0: slots geom[0], geom[2]; central difference in float64 on a float64 copy of the record
+    def fd(mutator, h):
+        vals = []
+        for sgn in (+1, -1):
+            prog = base.copy()
+            mutator(prog, sgn * h)
+            vals.append(objective(prog))
+        return (vals[0] - vals[1]) / (2 * h)
+
+    def set_c(s):
+        def m(prog, dh):
+            c = float(base["geom"][s][0]) + dh
+            prog["geom"][s][0] = c; prog["geom"][s][2] = c * (1 + float(base["geom"][s][1]))
+        return m
+    def set_tz(s):
+        def m(prog, dh):
+            prog["tj"][s][2] = float(base["tj"][s][2]) + dh
+        return m
+    def set_ts(c):
+        def m(prog, dh):
+            prog["ts"][:, c] = base["ts"][:, c] + dh
+        return m
+    h = 2e-3  # float32 records: large enough step for the differences, the objective is smooth
+    checks = [
+        (lens.shape.surfaces[0].c.grad, fd(set_c(0), h)),
+        (lens.shape.surfaces[1].c.grad, fd(set_c(1), h)),
+        (lens.shape.surfaces[0].transform.trans.grad[2], fd(set_tz(0), h)),
+        (lens.shape.surfaces[1].transform.trans.grad[2], fd(set_tz(1), h)),
+        (lens.shape.transform.trans.grad[0], fd(set_ts(0), h)),
+        (lens.shape.transform.trans.grad[2], fd(set_ts(2), h)),
+    ]
+    for got, want in checks:
+        assert abs(float(got) - want) <= 2e-2 * max(1.0, abs(want)), (float(got), want)
+    assert lens.shape.transform.rot_vec.grad is not None and torch.isfinite(lens.shape.transform.rot_vec.grad).all()
+    assert lens.ior_glass.grad is not None and lens.ior_media.grad is not None
+
+
+def test_no_grad_path_is_untouched(ns):
+    torch.manual_seed(0)
+    lens, sensor = scenes.spot_system(ns, grads=True)
+    rays = scenes.disk_bundle(ns).sample(1024).to(DEV)
+    with torch.no_grad():
+        out = ns.SequentialScene([lens, sensor]).simulate(rays)
+    assert out is rays and not out._pos.requires_grad
