@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--rays", type=int, default=64 * 2 ** 20, help="rays per GPU")
     ap.add_argument("--cpu-rays", type=int, default=2 ** 22, help="rays of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "spot"],
+                    help="singlet = the headline line; the others time the remaining configurations (informational)")
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
     ap.add_argument("--tune-blocks", type=int, default=0, help="override the grid cap for experiments")
     return ap.parse_args()
@@ -80,6 +82,95 @@ def cpu_baseline(n, scenes, ns):
                       f"{t * 1e3:.0f} ms per trace"}
 
 
+def other_workload(a, ns, scenes, dev, rank, world, dist):
+    """Configurations 3-5: 5-element system (16 Mi rays), 32-surface nearest-hit step (4 Mi rays), spot-size
+    loss forward+backward (singlet + sensor).  Same timing discipline as the headline line."""
+    defaults = {"system5": 16 * 2 ** 20, "naive32": 4 * 2 ** 20, "spot": 32 * 2 ** 20}
+    n = a.rays if a.rays != 64 * 2 ** 20 else defaults[a.workload]
+    pos, d = device_bundle(n, dev, 1000 + rank)
+    mk = lambda p, q: ns.Rays.from_planes(p, q, torch.ones(n, device=dev), torch.zeros(n, device=dev, dtype=torch.int8),
+                                          torch.zeros(n, device=dev))
+    rays = mk(pos, d)
+    kernel = "k_trace_seq"
+    if a.workload == "system5":
+        elements = scenes.system5(ns)
+        scene = ns.SequentialScene(elements)
+        out = mk(torch.empty_like(pos), torch.empty_like(d))
+        surfaces = 9
+
+        def step():
+            elements[-1].reset()
+            scene.simulate(rays, out=out)
+        bytes_per_ray = 56 + 1 + 17  # state in/out + sensor mask + (upper bound) one recorded hit
+    elif a.workload == "naive32":
+        scene = ns.Scene()
+        for el in scenes.naive32(ns):
+            scene.add_element(el)
+        rays._pos[2].fill_(-10.0)
+        work = rays.clone()
+        surfaces = 32
+        kernel = "k_step_nearest"
+
+        def step():
+            work._pos.copy_(rays._pos); work._dir.copy_(rays._dir); work.intensity.copy_(rays.intensity)
+            scene.elements[-1].reset()
+            scene.rays = work
+            scene.step()
+        bytes_per_ray = 56 + 1
+    else:
+        lens, sensor = scenes.spot_system(ns, grads=True)
+        scene = ns.SequentialScene([lens, sensor])
+        if dist is not None:
+            scene.grad_group = dist.group.WORLD
+        from raytracetorch_amd.optim.goals import spot_size_from_records
+        surfaces = 4
+        kernel = "k_trace_seq + k_trace_seq_tangent"
+
+        def step():
+            sensor.reset()
+            for p in scene.parameters():
+                p.grad = None
+            r = scene.simulate(rays.clone())
+            hit, w, mask, _ = sensor._dense[0]
+            loss = spot_size_from_records([(hit[0], hit[1], w, mask)], None, group=getattr(scene, "grad_group", None))
+            loss.backward()
+        bytes_per_ray = 108
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record(); step(); e.record()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gpu_ms = statistics.mean(s.elapsed_time(e) for s, e in ev)
+    if rank == 0:
+        achieved = bytes_per_ray * n / (gpu_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "ray-surface intersections/sec", "value": world * n * surfaces / (elapsed / a.steps),
+            "unit": "ray-surface intersections/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": a.workload, "rays_per_gpu": n, "surfaces": surfaces},
+            "rays_per_s": world * n / (elapsed / a.steps),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "kernel_ms": gpu_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_ray * n,
+                         "note": "event time spans every kernel of the step, including torch glue"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +194,9 @@ def main():
         _native.check(_native.lib().rtt_tune(0, a.tune_rpt), "rtt_tune")
     if a.tune_blocks:
         _native.check(_native.lib().rtt_tune(1, a.tune_blocks), "rtt_tune")
+
+    if a.workload != "singlet":
+        return other_workload(a, ns, scenes, dev, rank, world, dist)
 
     n = a.rays
     scene = ns.SequentialScene([scenes.singlet(ns)])

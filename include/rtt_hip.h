@@ -109,7 +109,7 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
 /* ---- backward of the sequential trace w.r.t. scene parameters (what torch autograd does to
  * scene/sequential.py:12-36 when c, k, trans, rot_vec, ior_* carry requires_grad; reached in the
  * reference through optim/goals.py:144-187 and tests/test_optimize_singlet.py:66-116).
- * Forward-mode: each ray is re-traced with n_theta (4 or 8) parameter directions; tan_dev is
+ * Forward-mode: each ray is re-traced with n_theta (2, 4, 6 or 8) parameter directions; tan_dev is
  * [n_surf][32][n_theta] = d(record slot)/d(theta_k) for the slots Rs[9], ts[3], Rj[9], tj[3], geom[4],
  * phys[4] in that order.  The per-ray tangents are contracted with the upstream adjoints of the output
  * rays (adj_pos, adj_dir: plane triples, nullable) and of the recorded sensor hit points

@@ -21,6 +21,12 @@ from . import _native as N
 from . import kernels as K
 from . import program as P
 
+from .sharding import allreduce_sum_
+
+# the float64 moment sums of SpotLossFn; a module attribute so that the multi-process CPU test can
+# substitute a host implementation (the product path has none)
+_spot_moments = K.spot_moments
+
 TAN_SLOTS = 32  # Rs[9] ts[3] Rj[9] tj[3] geom[4] phys[4]
 _SLOT_ORDER = (("Rs", 9), ("ts", 3), ("Rj", 9), ("tj", 3), ("geom", 4), ("phys", 4))
 
@@ -86,7 +92,7 @@ def tangent_table(elements, thetas) -> np.ndarray:
 
 
 def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
-    """sum_i <adjoint_i, d out_i / d theta_k> for all theta, in chunks of 8 (or 4) directions."""
+    """sum_i <adjoint_i, d out_i / d theta_k> for all theta, at most 8 directions per launch."""
     n = len(rays_in)
     dev = rays_in.device
     n_theta = table.shape[2]
@@ -98,7 +104,7 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
     for k0 in range(0, n_theta, 8):
         chunk = table[:, :, k0:k0 + 8]
-        width = 4 if chunk.shape[2] <= 4 else 8
+        width = max(2, chunk.shape[2] + (chunk.shape[2] & 1))  # kernels exist for 2, 4, 6 and 8 directions
         padded = np.zeros((table.shape[0], TAN_SLOTS, width), dtype=np.float32)
         padded[:, :, :chunk.shape[2]] = chunk
         tan_dev = torch.from_numpy(padded).to(dev)
@@ -139,9 +145,7 @@ class TraceSeqFn(torch.autograd.Function):
         if g_sens is not None and g_sens.numel() == 0:
             g_sens = None
         dtheta = _tangent_contract(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens)
-        if ctx.group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(dtheta, op=dist.ReduceOp.SUM, group=ctx.group)
+        allreduce_sum_(dtheta, ctx.group)
         grads = [torch.zeros(shape, dtype=torch.float64, device=dtheta.device) for shape, _, _ in ctx.param_meta]
         where = {pid: k for k, pid in enumerate(ctx.param_ids)}
         for k, (p, i) in enumerate(ctx.thetas):
@@ -178,18 +182,14 @@ class SpotLossFn(torch.autograd.Function):
     def forward(ctx, x, y, w, mask, target, group):
         mom = torch.zeros(4, device=x.device, dtype=torch.float64)
         xc, yc, wc = x.detach().contiguous(), y.detach().contiguous(), w.contiguous()
-        K.spot_moments(xc, yc, wc, mask, 0, 0.0, 0.0, 1.0, mom)
-        if group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=group)
+        _spot_moments(xc, yc, wc, mask, 0, 0.0, 0.0, 1.0, mom)
+        allreduce_sum_(mom, group)
         W, Sx, Sy, _ = mom.tolist()
         W = max(W, 1e-12)
         cx, cy = (Sx / W, Sy / W) if target is None else (float(target[0]), float(target[1]))
-        K.spot_moments(xc, yc, wc, mask, 1, cx, cy, W, mom)
-        loss = mom[3:4].clone()
-        if group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+        mom[3] = 0.0
+        _spot_moments(xc, yc, wc, mask, 1, cx, cy, W, mom)
+        loss = allreduce_sum_(mom[3:4].clone(), group)
         ctx.save_for_backward(xc, yc, wc, mask)
         ctx.consts = (cx, cy, W, target is None, group)
         return loss.reshape(()).to(torch.float32)
@@ -208,10 +208,7 @@ class SpotLossFn(torch.autograd.Function):
         inv = torch.where(u > 0, wn / u, torch.zeros_like(u))
         gx, gy = dx * inv, dy * inv
         if centroid:
-            G = torch.stack([gx.sum(dtype=torch.float64), gy.sum(dtype=torch.float64)])
-            if group is not None:
-                import torch.distributed as dist
-                dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+            G = allreduce_sum_(torch.stack([gx.sum(dtype=torch.float64), gy.sum(dtype=torch.float64)]), group)
             gx = gx - wn * G[0].to(gx.dtype)
             gy = gy - wn * G[1].to(gy.dtype)
         return gx * g, gy * g, None, None, None, None

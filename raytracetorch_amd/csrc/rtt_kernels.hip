@@ -1061,8 +1061,9 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
         a1 += wd * xd;
         a2 += wd * yd;
       } else {
-        const double dx = xd - cx, dy = yd - cy;
-        a0 += sqrt((dx * dx + dy * dy) * (wd / wsum));
+        // per-ray term in float32 like the reference's tensors, summed in float64
+        const float dx = (float)(xd - cx), dy = (float)(yd - cy);
+        a0 += (double)sqrtf((dx * dx + dy * dy) * (wi / (float)wsum));
       }
     }
   }
@@ -1107,6 +1108,15 @@ int grid_for(int64_t n, int rays_per_lane = 1) {
   const int64_t tile = (int64_t)kBlock * rays_per_lane;
   int64_t blocks = (n + tile - 1) / tile;
   if (blocks > g_max_blocks) blocks = g_max_blocks;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+// Kernels that end in one atomicAdd per block keep a bounded grid (grid-stride loop over the rays):
+// a hundred thousand blocks adding to the same few addresses serialise on the atomics.
+int grid_for_reduction(int64_t n) {
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -1205,7 +1215,7 @@ int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const fl
                               const float* tan_dev, int n_theta, const float* adj_pos, const float* adj_dir,
                               int64_t ld_adj, const float* adj_sens, int64_t sens_ld, double* dtheta, void* stream) {
   if (!pos_in || !dir_in || !inten_in || !prog_dev || !tan_dev || !dtheta) return RTT_E_NULL;
-  if (n < 0 || ld_in < n || (n_theta != 4 && n_theta != 8)) return RTT_E_SIZE;
+  if (n < 0 || ld_in < n || n_theta < 2 || n_theta > 8 || (n_theta & 1)) return RTT_E_SIZE;
   if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
   if (adj_sens && sens_ld < n) return RTT_E_SIZE;
   if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(tan_dev) || misaligned(adj_pos) ||
@@ -1218,10 +1228,13 @@ int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const fl
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
   TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta};
   const hipStream_t st = (hipStream_t)stream;
-  if (n_theta == 4)
-    hipLaunchKernelGGL(k_trace_seq_tangent<4>, dim3(grid_for(n)), dim3(kBlock), 0, st, io, prog_dev, n_surf, tio);
-  else
-    hipLaunchKernelGGL(k_trace_seq_tangent<8>, dim3(grid_for(n)), dim3(kBlock), 0, st, io, prog_dev, n_surf, tio);
+  const dim3 grid(grid_for_reduction(n)), block(kBlock);
+  switch (n_theta) {
+    case 2: hipLaunchKernelGGL(k_trace_seq_tangent<2>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 4: hipLaunchKernelGGL(k_trace_seq_tangent<4>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 6: hipLaunchKernelGGL(k_trace_seq_tangent<6>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    default: hipLaunchKernelGGL(k_trace_seq_tangent<8>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+  }
   return launch_status();
 }
 
@@ -1316,7 +1329,7 @@ int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const u
   if (n < 0 || (pass != 0 && pass != 1)) return RTT_E_SIZE;
   if (misaligned(x) || misaligned(y) || misaligned(w) || (reinterpret_cast<uintptr_t>(out) & 7u)) return RTT_E_ALIGN;
   if (n == 0) return RTT_OK;
-  hipLaunchKernelGGL(k_spot_moments, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w, mask, n,
+  hipLaunchKernelGGL(k_spot_moments, dim3(grid_for_reduction(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w, mask, n,
                      pass, cx, cy, wsum, out);
   return launch_status();
 }

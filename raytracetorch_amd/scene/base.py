@@ -76,7 +76,19 @@ class Scene(nn.Module):
         self.total_surfaces = len(el)
 
     def _program(self):
-        return P.compile_elements(self.elements)
+        """Packed surface program of the current elements; re-packed only when an element list entry or a
+        parameter (identity, storage or version counter) changed since the last call."""
+        els = tuple(id(el) for el in self.elements)
+        plist = getattr(self, "_param_list", None)
+        if plist is None or plist[0] != els:
+            plist = (els, list(self.parameters()))
+            self._param_list = plist
+        key = (els, tuple((p.data_ptr(), p._version) for p in plist[1]))
+        cached = getattr(self, "_prog_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, P.compile_elements(self.elements))
+            self._prog_cache = cached
+        return cached[1]
 
     def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask):
         if sens_hit is None:

@@ -1,0 +1,99 @@
+"""CPU, world_size 2 over gloo: the sharded spot-size loss (forward value and per-ray adjoints) equals the
+single-process value on the whole bundle.  The device moment kernel is replaced by a host stand-in for
+this test only; what is exercised is the sharding and the collectives around it."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracetorch_amd import sharding
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(10, 2, 2)
+    t = torch.ones(3)
+    assert sharding.allreduce_sum_(t, None) is t
+
+
+def _host_moments(x, y, w, mask, pass_id, cx, cy, wsum, out):
+    """Host stand-in with the semantics of rtt_spot_moments_f32 (float64 accumulation)."""
+    on = (w > 0) if mask is None else ((w > 0) & mask.bool())
+    xd, yd, wd = x.double()[on], y.double()[on], w.double()[on]
+    if pass_id == 0:
+        out[0] += wd.sum(); out[1] += (wd * xd).sum(); out[2] += (wd * yd).sum()
+    else:
+        out[3] += torch.sqrt(((xd - cx) ** 2 + (yd - cy) ** 2) * (wd / wsum)).sum()
+    return out
+
+
+def _data(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, generator=g) * 0.3 + 0.1
+    y = torch.randn(n, generator=g) * 0.2 - 0.05
+    w = (torch.rand(n, generator=g) > 0.2).float()
+    mask = (torch.rand(n, generator=g) > 0.1).to(torch.uint8)
+    return x, y, w, mask
+
+
+def _single_process(x, y, w, mask, target):
+    x = x.clone().requires_grad_(True); y = y.clone().requires_grad_(True)
+    act = (w > 0) & mask.bool()
+    xa, ya, wa = x[act].double(), y[act].double(), w[act].double()
+    W = wa.sum().clamp(min=1e-12)
+    cx, cy = ((xa * wa).sum() / W, (ya * wa).sum() / W) if target is None else target
+    loss = torch.sqrt(((xa - cx) ** 2 + (ya - cy) ** 2) * (wa / W)).sum()
+    loss.backward()
+    return float(loss), x.grad, y.grad
+
+
+def _worker(rank, world, port, n, target, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracetorch_amd import autograd as AG
+        AG._spot_moments = _host_moments
+        x, y, w, mask = _data(n)
+        lo, hi = sharding.shard_bounds(n, rank, world)
+        xs = x[lo:hi].clone().requires_grad_(True); ys = y[lo:hi].clone().requires_grad_(True)
+        loss = AG.SpotLossFn.apply(xs, ys, w[lo:hi], mask[lo:hi], target, dist.group.WORLD)
+        loss.backward()
+        # parameter-gradient vectors are summed the same way
+        dtheta = sharding.allreduce_sum_(torch.tensor([float(rank + 1), 2.0], dtype=torch.float64), dist.group.WORLD)
+        ret[rank] = (float(loss), xs.grad.clone(), ys.grad.clone(), lo, hi, dtheta.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("target", [None, (0.05, -0.02)])
+def test_sharded_spot_loss_equals_single_process(target):
+    n, world = 10001, 2
+    x, y, w, mask = _data(n)
+    want_loss, want_gx, want_gy = _single_process(x, y, w, mask, target)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, target, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        loss, gx, gy, lo, hi, dtheta = ret[rank]
+        assert abs(loss - want_loss) / want_loss < 1e-6            # every rank holds the global loss
+        assert torch.allclose(gx, want_gx[lo:hi], rtol=1e-4, atol=1e-7)
+        assert torch.allclose(gy, want_gy[lo:hi], rtol=1e-4, atol=1e-7)
+        assert dtheta == [3.0, 4.0]
