@@ -60,6 +60,17 @@ def device_bundle(n, device, seed):
     return pos, d
 
 
+def measured_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (None if the
+    ray count differs from the profiled one)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_singlet.json")), reverse=True):
+        d = json.load(open(f))
+        if d.get("rays_per_gpu") == n:
+            return d["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(n, scenes, ns):
     """The CPU oracle (a torch-CPU port of the reference's per-ray arithmetic) on a bounded sample."""
     import rtt_oracle as O
@@ -245,7 +256,7 @@ def main():
                        "alive_after_trace_rank0": alive},
             "rays_per_s": world * n / (elapsed / a.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_trace_seq",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n), "kernel": "k_trace_seq",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": BYTES_PER_RAY * n},
         }
         if world == 1 and not a.no_cpu_baseline:
