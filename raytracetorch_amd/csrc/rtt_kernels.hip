@@ -880,77 +880,126 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
 // Scene.ray_cast / Scene.step (scene/base.py:144-235)
 // ------------------------------------------------------------------------------------------------
 // torch.min(t_matrix, dim=1): first index of the smallest value, NaN wins and sticks.
-DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<float> p, V3<float> d,
-                float& tmin, int& win) {
-  tmin = kInf;
-  win = 0;
+// Every ray tests every surface, so the cast runs on packed lanes (two rays per lane) like the
+// sequential trace; `win` is an int per component.
+DI int isel(bool m, int a, int b) { return m ? a : b; }
+DI i2 isel(i2 m, int a, i2 b) { return m ? i2(a) : b; }
+template <class T> struct WinOf { using type = int; };
+template <> struct WinOf<f2> { using type = i2; };
+DI int icomp(int a, int) { return a; }
+DI int icomp(i2 a, int k) { return k == 0 ? a.x : a.y; }
+
+template <class T>
+DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
+                typename WinOf<T>::type& win) {
+  tmin = splat<T>(kInf);
+  win = typename WinOf<T>::type(0);
   for (int s = 0; s < n_surf; ++s) {
     const RecF S{prog[s]};
-    Frames<float> f;
-    float t_raw = kInf, t = kInf;
+    Frames<T> f;
+    T t_raw = splat<T>(kInf), t = splat<T>(kInf);
 #define RTT_CALL(CFG)                                          \
   {                                                            \
-    const bool valid = test_surface<CFG>(S, p, d, f, t_raw);   \
+    const auto valid = test_surface<CFG>(S, p, d, f, t_raw);   \
     t = masked_t<CFG>(S, t_raw, valid);                        \
   }
     RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
-    const bool take = (tmin == tmin) && ((t != t) || (t < tmin));
-    if (take) {
-      tmin = t;
-      win = s;
-    }
+    const auto take = and_(not_(isnan_(tmin)), or_(isnan_(t), lt(t, tmin)));
+    tmin = sel(take, t, tmin);
+    win = isel(take, s, win);
   }
-  if (!(tmin < kInf)) win = -1;
+  win = isel(not_(lt(tmin, splat<T>(kInf))), -1, win);
 }
 
+template <class T>
 __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ pos, const float* __restrict__ dir,
                                                      int64_t ld, int64_t n, const RttSurface* __restrict__ prog_,
                                                      int n_surf, Ops ops, int32_t* __restrict__ winner,
-                                                     float* __restrict__ tmin_out) {
+                                                     float* __restrict__ tmin_out, int vec) {
+  constexpr int N = LaneOf<T>::N;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
-    V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
-    float tmin;
-    int win;
-    nearest(prog, n_surf, ops, p, d, tmin, win);
-    if (winner) winner[i] = win;
-    if (tmin_out) tmin_out[i] = tmin;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * N;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < n; i += stride) {
+    const int nv = (n - i) >= N ? N : 1;
+    T* tag = nullptr;
+    V3<T> p = {ld_(pos, i, vec != 0, nv, tag), ld_(pos + ld, i, vec != 0, nv, tag), ld_(pos + 2 * ld, i, vec != 0, nv, tag)};
+    V3<T> d = {ld_(dir, i, vec != 0, nv, tag), ld_(dir + ld, i, vec != 0, nv, tag), ld_(dir + 2 * ld, i, vec != 0, nv, tag)};
+    T tmin;
+    typename WinOf<T>::type win;
+    nearest<T>(prog, n_surf, ops, p, d, tmin, win);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (k >= nv) break;
+      if (winner) winner[i + k] = icomp(win, k);
+      if (tmin_out) tmin_out[i + k] = comp(tmin, k);
+    }
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                         Ops ops, int32_t* __restrict__ winner, SensorIO se) {
-  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
-    Ray<float> r = load_ray<float>(io, i);
-    float tmin;
-    int win;
-    nearest(prog, n_surf, ops, r.p, r.d, tmin, win);
-    if (winner) winner[i] = win;
-    // active_mask = hit & (intensity > 0), scene/base.py:201
-    bool pending = (win >= 0) && (r.I > 0.0f);
-    // Lanes of one wavefront may have won different surfaces: serve one surface per pass with its
-    // record held in scalar registers (readfirstlane picks the surface of the first pending lane).
-    while (pending) {
-      const int s = __builtin_amdgcn_readfirstlane(win);
-      if (win == s) {
-        const RecF S{prog[s]};
+// one ray of a lane through the surface it won (Element.forward + scatter_update, scene/base.py:213-235)
+// `t` is the winner's distance from the cast itself: the reference recomputes it in Element.forward with
+// the very operations of intersectTest, so both agree there by construction; re-solving here with a
+// differently contracted instruction stream could flip the `t <= 1e-6` filter for rays that start on a
+// surface (every bounce after the first) and turn a finite hit into an infinite one.
+DI void serve_winner(const RttSurface* __restrict__ prog, const Ops& ops, int win, float t, Ray<float>& r,
+                     const SensorIO& se, int64_t i) {
+  // active_mask = hit & (intensity > 0), scene/base.py:201
+  bool pending = (win >= 0) && (r.I > 0.0f);
+  // Lanes of one wavefront may have won different surfaces: serve one surface per pass with its
+  // record held in scalar registers (readfirstlane picks the surface of the first pending lane).
+  while (pending) {
+    const int s = __builtin_amdgcn_readfirstlane(win);
+    if (win == s) {
+      const RecF S{prog[s]};
 #define RTT_CALL(CFG)                                  \
   {                                                    \
     Frames<float> f = to_frames<CFG>(S, r.p, r.d);     \
-    const float t_raw = solve_t<CFG>(S, f);            \
-    interact<CFG>(S, f, t_raw, true, r, se, i);        \
+    interact<CFG>(S, f, t, true, r, se, i);            \
   }
-        RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
-        pending = false;
+      pending = false;
+    }
+  }
+}
+
+DI Ray<float> ray_comp(const Ray<float>& r, int) { return r; }
+DI Ray<float> ray_comp(const Ray<f2>& r, int k) {
+  return {{comp(r.p.x, k), comp(r.p.y, k), comp(r.p.z, k)}, {comp(r.d.x, k), comp(r.d.y, k), comp(r.d.z, k)}, comp(r.I, k)};
+}
+DI void ray_set(Ray<float>& r, int, const Ray<float>& v) { r = v; }
+DI void ray_set(Ray<f2>& r, int k, const Ray<float>& v) {
+  if (k == 0) {
+    r.p.x.x = v.p.x; r.p.y.x = v.p.y; r.p.z.x = v.p.z; r.d.x.x = v.d.x; r.d.y.x = v.d.y; r.d.z.x = v.d.z; r.I.x = v.I;
+  } else {
+    r.p.x.y = v.p.x; r.p.y.y = v.p.y; r.p.z.y = v.p.z; r.d.x.y = v.d.x; r.d.y.y = v.d.y; r.d.z.y = v.d.z; r.I.y = v.I;
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                         Ops ops, int32_t* __restrict__ winner, SensorIO se, int vec) {
+  constexpr int N = LaneOf<T>::N;
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
+  const int64_t stride = (int64_t)gridDim.x * kBlock * N;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < io.n; i += stride) {
+    const int nv = (io.n - i) >= N ? N : 1;
+    Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
+    T tmin;
+    typename WinOf<T>::type win;
+    nearest<T>(prog, n_surf, ops, r.p, r.d, tmin, win);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (k < nv) {
+        const int wk = icomp(win, k);
+        if (winner) winner[i + k] = wk;
+        Ray<float> rk = ray_comp(r, k);
+        serve_winner(prog, ops, wk, comp(tmin, k), rk, se, i + k);
+        ray_set(r, k, rk);
       }
     }
-    store_ray<float>(io, i, r);
+    store_ray<T>(io, i, r, vec != 0, nv);
   }
 }
 
@@ -1246,8 +1295,9 @@ int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, 
   int rc = check_program(prog_host, n_surf, nullptr, nullptr);
   if (rc != RTT_OK) return rc;
   if (n == 0) return RTT_OK;
-  hipLaunchKernelGGL(k_ray_cast, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, pos, dir, ld, n,
-                     prog_dev, n_surf, make_ops(prog_host, n_surf), winner, tmin);
+  const int vec = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(dir)) & 7u) == 0;
+  hipLaunchKernelGGL(k_ray_cast<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, pos, dir, ld, n,
+                     prog_dev, n_surf, make_ops(prog_host, n_surf), winner, tmin, vec);
   return launch_status();
 }
 
@@ -1270,8 +1320,11 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
-  hipLaunchKernelGGL(k_step_nearest, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
-                     n_surf, make_ops(prog_host, n_surf), winner, se);
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
+                  aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+  hipLaunchKernelGGL(k_step_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+                     n_surf, make_ops(prog_host, n_surf), winner, se, vec);
   return launch_status();
 }
 
