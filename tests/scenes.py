@@ -176,3 +176,31 @@ def kat_rays(ns):
                          lambda: R([[0, 0, -20], [1, 1, -20], [5, 5, -20], [0.1, 8, -20]],
                                    [[0, 0, 1], [0, 0, 1], [0, 0.1, 1], [0, 0.1, 1]])),
     }
+
+
+def random_system(ns, rng):
+    """The same random constructor arguments for either namespace."""
+    els = []
+    z = 0.0
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.choice(["singlet", "singlet", "doublet", "stop", "mirror", "cyl"])
+        rot = [float(x) for x in rng.normal(0, 0.03, 3)] if rng.random() < 0.5 else None
+        tr = ns.RayTransform(translation=[float(rng.normal(0, 0.2)), float(rng.normal(0, 0.2)), z], rotation=rot)
+        if kind == "singlet":
+            els.append(ns.SingletLens(c1=float(rng.uniform(-0.06, 0.06)), c2=float(rng.uniform(-0.06, 0.06)), d=12.0,
+                                      t=float(rng.uniform(3.0, 5.0)), ior_glass=float(rng.uniform(1.4, 1.9)),
+                                      inked=bool(rng.random() < 0.5), transform=tr))
+        elif kind == "doublet":
+            els.append(ns.DoubletLens(c1=float(rng.uniform(0.0, 0.05)), c2=float(rng.uniform(-0.04, 0.0)),
+                                      c3=float(rng.uniform(-0.03, 0.01)), d=12.0, t1=3.0, t2=2.0,
+                                      ior_glass1=1.5, ior_glass2=float(rng.uniform(1.55, 1.8)), transform=tr))
+        elif kind == "stop":
+            els.append(ns.CircularAperture(float(rng.uniform(2.0, 4.0)), invert=True, transform=tr))
+        elif kind == "mirror":
+            els.append(ns.SphericalMirror(c1=float(rng.uniform(-0.03, 0.03)), d=0.0, diameter=20.0, transform=tr))
+        else:
+            els.append(ns.CylSingletLens(c1=float(rng.uniform(0.0, 0.05)), c2=float(rng.uniform(-0.05, 0.0)), height=12.0,
+                                         width=11.0, t=3.0, ior_glass=1.6, inked=bool(rng.random() < 0.5), transform=tr))
+        z += float(rng.uniform(6.0, 10.0))
+    els.append(ns.Sensor(ns.Disk(15.0, transform=ns.RayTransform(translation=[0.0, 0.0, z]))))
+    return els
