@@ -133,18 +133,19 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         scene = ns.SequentialScene([lens, sensor])
         if dist is not None:
             scene.grad_group = dist.group.WORLD
-        from raytracetorch_amd.optim.goals import spot_size_from_records
         surfaces = 4
-        kernel = "k_trace_seq + k_trace_seq_tangent"
+        kernel = "k_trace_seq + k_spot_moments + k_trace_seq_tangent<6, spot>"
+
+        class _Resident(torch.nn.Module):
+            """Bundle stand-in for SpotSizeLoss: hands out the resident synthetic rays."""
+            def sample(self, _n):
+                return ns.Rays.from_planes(rays._pos, rays._dir, rays.intensity, rays.id, rays.wavelength)
+        loss_fn = ns.SpotSizeLoss(sensor, [_Resident()], N_rays=n)
 
         def step():
-            sensor.reset()
             for p in scene.parameters():
                 p.grad = None
-            r = scene.simulate(rays.clone())
-            hit, w, mask, _ = sensor._dense[0]
-            loss = spot_size_from_records([(hit[0], hit[1], w, mask)], None, group=getattr(scene, "grad_group", None))
-            loss.backward()
+            loss_fn(scene).backward()
         bytes_per_ray = 108
 
     def barrier():

@@ -120,6 +120,18 @@ int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const fl
                               const float* tan_dev, int n_theta, const float* adj_pos, const float* adj_dir,
                               int64_t ld_adj, const float* adj_sens, int64_t sens_ld, double* dtheta, void* stream);
 
+/* ---- fused backward of the spot-size loss (optim/goals.py:144-187 followed by .backward()):
+ * the same tangent trace, with the loss adjoint formed in the kernel from the primal hit point on sensor
+ * slot `sensor_slot`, g = (x-cx, y-cy)(w/W)/sqrt(((x-cx)^2+(y-cy)^2) w/W) for hits with intensity w > 0.
+ * out[3*n_theta + 2] (float64, device, zeroed by the caller) receives
+ *   A_k = sum g . d(hit_xy)/d theta_k,  Bx_k = sum (w/W) dx/d theta_k,  By_k = sum (w/W) dy/d theta_k,  Gx, Gy = sum g,
+ * from which dL/d theta_k = A_k - Gx Bx_k - Gy By_k (centroid as reference point) or A_k (fixed target).
+ * All five are plain sums over rays, so ranks add them before combining. */
+int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                                const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                                const float* tan_dev, int n_theta, int sensor_slot, double cx, double cy, double wsum,
+                                double* out, void* stream);
+
 /* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
  * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
  * tmin[i] = that t.  Either output may be NULL. */

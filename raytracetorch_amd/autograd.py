@@ -102,11 +102,8 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     dp = N.DeviceProgram.upload(prog, dev)
     fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
     adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
-    for k0 in range(0, n_theta, 8):
-        chunk = table[:, :, k0:k0 + 8]
-        width = max(2, chunk.shape[2] + (chunk.shape[2] & 1))  # kernels exist for 2, 4, 6 and 8 directions
-        padded = np.zeros((table.shape[0], TAN_SLOTS, width), dtype=np.float32)
-        padded[:, :, :chunk.shape[2]] = chunk
+    for k0, used, padded in _chunks(table):  # kernels exist for 2, 4, 6 and 8 directions
+        width = padded.shape[2]
         tan_dev = torch.from_numpy(padded).to(dev)
         acc = torch.zeros(width, dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
@@ -115,7 +112,7 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
                 N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width,
                 N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n, N.ptr(acc), N.stream_handle(dev))
         N.check(code, "rtt_trace_seq_tangent_f32")
-        out[k0:k0 + chunk.shape[2]] = acc[:chunk.shape[2]]
+        out[k0:k0 + used] = acc[:used]
     return out
 
 
@@ -128,7 +125,9 @@ class TraceSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_in, prog, table, thetas, group, *params):
         from .rays.ray import Rays
-        out = rays_in.clone()
+        # the kernel writes every ray of `out`, so fresh uninitialised planes are enough
+        out = Rays.from_planes(torch.empty_like(rays_in._pos), torch.empty_like(rays_in._dir),
+                               torch.empty_like(rays_in.intensity), rays_in.id, rays_in.wavelength)
         sens_hit, sens_w, sens_mask = K.trace_sequential(rays_in, prog, out=out)
         ctx.rays_in, ctx.prog, ctx.table, ctx.thetas, ctx.group = rays_in, prog, table, thetas, group
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
@@ -212,3 +211,80 @@ class SpotLossFn(torch.autograd.Function):
             gx = gx - wn * G[0].to(gx.dtype)
             gy = gy - wn * G[1].to(gy.dtype)
         return gx * g, gy * g, None, None, None, None
+
+
+def _chunks(table):
+    """Yield (k0, width_used, padded [n_surf, 32, width]) with width in {2, 4, 6, 8}."""
+    n_theta = table.shape[2]
+    for k0 in range(0, n_theta, 8):
+        chunk = table[:, :, k0:k0 + 8]
+        used = chunk.shape[2]
+        width = max(2, used + (used & 1))
+        padded = np.zeros((table.shape[0], TAN_SLOTS, width), dtype=np.float32)
+        padded[:, :, :used] = chunk
+        yield k0, used, padded
+
+
+class FusedSpotLossFn(torch.autograd.Function):
+    """Spot-size loss of a sequential scene as ONE differentiable function of the scene parameters
+    (optim/goals.py:144-187): forward = trace + float64 moments, backward = one tangent trace that forms the
+    loss adjoint in the kernel (rtt_trace_seq_spot_grad_f32).  No per-ray adjoint or tangent ever reaches HBM."""
+
+    @staticmethod
+    def forward(ctx, rays_in, prog, table, thetas, group, target, sensor_slot, sens, *params):
+        hit, w, mask = sens  # dense record of the sensor slot from the forward trace
+        mom = torch.zeros(4, device=w.device, dtype=torch.float64)
+        x, y = hit[0], hit[1]
+        _spot_moments(x, y, w, mask, 0, 0.0, 0.0, 1.0, mom)
+        allreduce_sum_(mom, group)
+        W, Sx, Sy, _ = mom.tolist()
+        W = max(W, 1e-12)
+        cx, cy = (Sx / W, Sy / W) if target is None else (float(target[0]), float(target[1]))
+        mom[3] = 0.0
+        _spot_moments(x, y, w, mask, 1, cx, cy, W, mom)
+        loss = allreduce_sum_(mom[3:4].clone(), group)
+        ctx.state = (rays_in, prog, table, thetas, group, target is None, sensor_slot, cx, cy, W)
+        ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
+        ctx.param_ids = [id(p) for p in params]
+        return loss.reshape(()).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        rays_in, prog, table, thetas, group, centroid, slot, cx, cy, W = ctx.state
+        n, dev = len(rays_in), rays_in.device
+        dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
+        dp = N.DeviceProgram.upload(prog, dev)
+        for k0, used, padded in _chunks(table):
+            width = padded.shape[2]
+            tan_dev = torch.from_numpy(padded).to(dev)
+            out = torch.zeros(3 * width + 2, dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                code = N.lib().rtt_trace_seq_spot_grad_f32(
+                    N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+                    N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width, int(slot), cx, cy, W,
+                    N.ptr(out), N.stream_handle(dev))
+            N.check(code, "rtt_trace_seq_spot_grad_f32")
+            allreduce_sum_(out, group)
+            A, Bx, By = out[:width], out[width:2 * width], out[2 * width:3 * width]
+            d = A - out[3 * width] * Bx - out[3 * width + 1] * By if centroid else A
+            dtheta[k0:k0 + used] = d[:used]
+        dtheta = dtheta * g.to(torch.float64)
+        grads = [torch.zeros(shape, dtype=torch.float64, device=dev) for shape, _, _ in ctx.param_meta]
+        where = {pid: k for k, pid in enumerate(ctx.param_ids)}
+        for k, (p, i) in enumerate(thetas):
+            grads[where[id(p)]].view(-1)[i] = dtheta[k]
+        grads = [gr.to(device=d_, dtype=dt) for gr, (_, dt, d_) in zip(grads, ctx.param_meta)]
+        return (None,) * 8 + tuple(grads)
+
+
+def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None):
+    """Differentiable spot-size loss of a bundle already traced (forward only, no graph) through `prog`;
+    `sens` = (hit [3,N], w [N], mask [N]) of the sensor slot, `rays` the *input* bundle of that trace."""
+    thetas = trainable_scalars(elements)
+    table = tangent_table(elements, thetas)
+    params, seen = [], set()
+    for p, _ in thetas:
+        if id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    return FusedSpotLossFn.apply(rays, prog, table, thetas, group, target, sensor_slot, sens, *params)

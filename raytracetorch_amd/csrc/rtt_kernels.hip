@@ -117,26 +117,28 @@ DI bool mcomp(i2 m, int k) { return (k == 0 ? m.x : m.y) != 0; }
 // ------------------------------------------------------------------------------------------------
 template <int K>
 struct Dual {
+  static_assert(K % 2 == 0, "tangents are stored as packed pairs");
   float v;
-  float t[K];
+  f2 tp[K / 2];  // tangent 2j in .x, 2j+1 in .y: the tangent arithmetic runs on v_pk_*_f32
   DI Dual() {}
   DI Dual(float x) : v(x) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) t[k] = 0.0f;
+    for (int j = 0; j < K / 2; ++j) tp[j] = f2(0.0f);
   }
+  DI float tan(int k) const { return (k & 1) ? tp[k >> 1].y : tp[k >> 1].x; }
 };
 template <int K> struct LaneOf<Dual<K>> { using M = bool; static constexpr int N = 1; };
 
-#define RTT_DUAL_LOOP _Pragma("unroll") for (int k = 0; k < K; ++k)
-template <int K> DI Dual<K> operator+(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v + b.v; RTT_DUAL_LOOP r.t[k] = a.t[k] + b.t[k]; return r; }
-template <int K> DI Dual<K> operator-(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v - b.v; RTT_DUAL_LOOP r.t[k] = a.t[k] - b.t[k]; return r; }
-template <int K> DI Dual<K> operator*(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v * b.v; RTT_DUAL_LOOP r.t[k] = a.t[k] * b.v + a.v * b.t[k]; return r; }
-template <int K> DI Dual<K> operator-(Dual<K> a) { Dual<K> r; r.v = -a.v; RTT_DUAL_LOOP r.t[k] = -a.t[k]; return r; }
+#define RTT_DUAL_LOOP _Pragma("unroll") for (int j = 0; j < K / 2; ++j)
+template <int K> DI Dual<K> operator+(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v + b.v; RTT_DUAL_LOOP r.tp[j] = a.tp[j] + b.tp[j]; return r; }
+template <int K> DI Dual<K> operator-(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v - b.v; RTT_DUAL_LOOP r.tp[j] = a.tp[j] - b.tp[j]; return r; }
+template <int K> DI Dual<K> operator*(Dual<K> a, Dual<K> b) { Dual<K> r; r.v = a.v * b.v; RTT_DUAL_LOOP r.tp[j] = a.tp[j] * b.v + a.v * b.tp[j]; return r; }
+template <int K> DI Dual<K> operator-(Dual<K> a) { Dual<K> r; r.v = -a.v; RTT_DUAL_LOOP r.tp[j] = -a.tp[j]; return r; }
 template <int K> DI Dual<K> operator+(Dual<K> a, float b) { a.v += b; return a; }
 template <int K> DI Dual<K> operator+(float a, Dual<K> b) { b.v += a; return b; }
 template <int K> DI Dual<K> operator-(Dual<K> a, float b) { a.v -= b; return a; }
 template <int K> DI Dual<K> operator-(float a, Dual<K> b) { return (-b) + a; }
-template <int K> DI Dual<K> operator*(Dual<K> a, float b) { a.v *= b; RTT_DUAL_LOOP a.t[k] *= b; return a; }
+template <int K> DI Dual<K> operator*(Dual<K> a, float b) { a.v *= b; RTT_DUAL_LOOP a.tp[j] = a.tp[j] * b; return a; }
 template <int K> DI Dual<K> operator*(float a, Dual<K> b) { return b * a; }
 template <int K> DI bool lt(Dual<K> a, Dual<K> b) { return a.v < b.v; }
 template <int K> DI bool le(Dual<K> a, Dual<K> b) { return a.v <= b.v; }
@@ -148,7 +150,7 @@ template <int K> DI Dual<K> abs_(Dual<K> a) { return a.v < 0.0f ? -a : (a.v > 0.
 template <int K> DI Dual<K> max_(Dual<K> a, Dual<K> b) { return (a.v > b.v || b.v != b.v) ? a : b; }
 template <int K> DI Dual<K> min_(Dual<K> a, Dual<K> b) { return (a.v < b.v || b.v != b.v) ? a : b; }
 // f(a) with derivative fp: chain rule on every tangent
-template <int K> DI Dual<K> chain(Dual<K> a, float f, float fp) { Dual<K> r; r.v = f; RTT_DUAL_LOOP r.t[k] = fp * a.t[k]; return r; }
+template <int K> DI Dual<K> chain(Dual<K> a, float f, float fp) { Dual<K> r; r.v = f; RTT_DUAL_LOOP r.tp[j] = a.tp[j] * fp; return r; }
 template <int K> DI Dual<K> rcp_(Dual<K> a) { const float r = rcp_(a.v); return chain(a, r, -r * r); }
 template <int K> DI Dual<K> sqrt_(Dual<K> a) { const float s = sqrt_(a.v); return chain(a, s, 0.5f * rcp_(s)); }
 template <int K> DI Dual<K> sqrt_disc(Dual<K> a) { const float s = sqrt_disc(a.v); return chain(a, s, 0.5f * rcp_(s)); }
@@ -261,7 +263,7 @@ struct RecD {
     Dual<K> d;
     d.v = v;
 #pragma unroll
-    for (int k = 0; k < K; ++k) d.t[k] = tan[slot * K + k];
+    for (int j = 0; j < K / 2; ++j) d.tp[j] = f2{tan[slot * K + 2 * j], tan[slot * K + 2 * j + 1]};
     return d;
   }
   DI Dual<K> Rs(int i) const { return mk(r.Rs[i], i); }
@@ -812,17 +814,25 @@ struct TangentIO {
   int64_t ld_adj;
   const float* adj_sens;  // [slots][3][sens_ld] or null
   int64_t sens_ld;
-  double* dtheta;  // [K]
+  double* dtheta;  // [K], or [3K + 2] in spot mode
+  // spot mode (SPOT = true): the upstream adjoint of the spot-size loss is formed in the kernel from the
+  // primal hit point on sensor slot `spot_slot`:  g = (x - cx, y - cy) (w/W) / sqrt(((x-cx)^2+(y-cy)^2) w/W)
+  int spot_slot;
+  float cx, cy, inv_w;
 };
 
-template <int K>
+// NACC accumulators per lane: K (plain) or 3K + 2 (spot: A_k = sum g.dhit_k, Bx_k = sum (w/W) dx_k,
+// By_k = sum (w/W) dy_k, Gx = sum gx, Gy = sum gy; the host forms dL/dtheta_k = A_k - Gx Bx_k - Gy By_k
+// when the centroid is the reference point, optim/goals.py:176-182).
+template <int K, bool SPOT>
 __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
                                                               TangentIO tio) {
   using T = Dual<K>;
-  __shared__ double part[K][kBlock / 64];
-  double acc[K];
+  constexpr int NACC = SPOT ? 3 * K + 2 : K;
+  __shared__ double part[NACC][kBlock / 64];
+  float acc[NACC];  // a lane adds at most n / (2048 * 256) terms here; the cross-lane sums are float64
 #pragma unroll
-  for (int k = 0; k < K; ++k) acc[k] = 0.0;
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
     Ray<float> r0 = load_ray<float>(io, i);
@@ -840,36 +850,55 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
       V3<T> nd;
       T im;
       apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im);
-      if ((S.r.flags & RTT_F_SENSOR) && tio.adj_sens) {
-        const float* a = tio.adj_sens + (int64_t)S.r.sensor_slot * 3 * tio.sens_ld + i;
-        const float ax = a[0], ay = a[tio.sens_ld], az = a[2 * tio.sens_ld];
+      if (S.r.flags & RTT_F_SENSOR) {
+        if (SPOT) {
+          const float w = r.I.v;
+          if (S.r.sensor_slot == tio.spot_slot && w > 0.0f) {
+            const float wn = w * tio.inv_w;
+            const float dx = fw.hit_l.x.v - tio.cx, dy = fw.hit_l.y.v - tio.cy;
+            const float u = sqrtf((dx * dx + dy * dy) * wn);
+            const float inv = u > 0.0f ? wn / u : 0.0f;
+            const float gx = dx * inv, gy = dy * inv;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          acc[k] += (double)(ax * fw.hit_l.x.t[k] + ay * fw.hit_l.y.t[k] + az * fw.hit_l.z.t[k]);
+            for (int k = 0; k < K; ++k) {
+              const float tx = fw.hit_l.x.tan(k), ty = fw.hit_l.y.tan(k);
+              acc[k] += gx * tx + gy * ty;
+              acc[K + k] += wn * tx;
+              acc[2 * K + k] += wn * ty;
+            }
+            acc[3 * K] += gx;
+            acc[3 * K + 1] += gy;
+          }
+        } else if (tio.adj_sens) {
+          const float* a = tio.adj_sens + (int64_t)S.r.sensor_slot * 3 * tio.sens_ld + i;
+          const float ax = a[0], ay = a[tio.sens_ld], az = a[2 * tio.sens_ld];
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k] += ax * fw.hit_l.x.tan(k) + ay * fw.hit_l.y.tan(k) + az * fw.hit_l.z.tan(k);
+        }
       }
       r.p = fw.hit_g;
       r.d = nd;
       r.I = r.I * im;
     }
-    if (tio.adj_pos) {
+    if (!SPOT && tio.adj_pos) {
       const float ax = tio.adj_pos[i], ay = tio.adj_pos[tio.ld_adj + i], az = tio.adj_pos[2 * tio.ld_adj + i];
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc[k] += (double)(ax * r.p.x.t[k] + ay * r.p.y.t[k] + az * r.p.z.t[k]);
+      for (int k = 0; k < K; ++k) acc[k] += ax * r.p.x.tan(k) + ay * r.p.y.tan(k) + az * r.p.z.tan(k);
     }
-    if (tio.adj_dir) {
+    if (!SPOT && tio.adj_dir) {
       const float ax = tio.adj_dir[i], ay = tio.adj_dir[tio.ld_adj + i], az = tio.adj_dir[2 * tio.ld_adj + i];
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc[k] += (double)(ax * r.d.x.t[k] + ay * r.d.y.t[k] + az * r.d.z.t[k]);
+      for (int k = 0; k < K; ++k) acc[k] += ax * r.d.x.tan(k) + ay * r.d.y.tan(k) + az * r.d.z.tan(k);
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const double v = wave_sum(acc[k]);
+  for (int k = 0; k < NACC; ++k) {
+    const double v = wave_sum((double)acc[k]);
     if (lane == 0) part[k][wv] = v;
   }
   __syncthreads();
-  if (threadIdx.x < K) {
+  if (threadIdx.x < NACC) {
     double sum = 0.0;
     for (int w = 0; w < kBlock / 64; ++w) sum += part[threadIdx.x][w];
     atomicAdd(&tio.dtheta[threadIdx.x], sum);
@@ -1259,32 +1288,64 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
   return launch_status();
 }
 
+}  // extern "C"
+
+namespace {
+
+template <bool SPOT>
+int launch_tangent(RayIO io, const RttSurface* prog_dev, int n_surf, const TangentIO& tio, int n_theta, hipStream_t st) {
+  const dim3 grid(grid_for_reduction(io.n)), block(kBlock);
+  switch (n_theta) {
+    case 2: hipLaunchKernelGGL((k_trace_seq_tangent<2, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 4: hipLaunchKernelGGL((k_trace_seq_tangent<4, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 6: hipLaunchKernelGGL((k_trace_seq_tangent<6, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    default: hipLaunchKernelGGL((k_trace_seq_tangent<8, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+  }
+  return launch_status();
+}
+
+int check_tangent_args(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                       const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const float* tan_dev,
+                       int n_theta, const double* out) {
+  if (!pos_in || !dir_in || !inten_in || !prog_dev || !tan_dev || !out) return RTT_E_NULL;
+  if (n < 0 || ld_in < n || n_theta < 2 || n_theta > 8 || (n_theta & 1)) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(tan_dev) ||
+      (reinterpret_cast<uintptr_t>(out) & 7u))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  return check_program(prog_host, n_surf, &any_sensor, nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
 int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
                               const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
                               const float* tan_dev, int n_theta, const float* adj_pos, const float* adj_dir,
                               int64_t ld_adj, const float* adj_sens, int64_t sens_ld, double* dtheta, void* stream) {
-  if (!pos_in || !dir_in || !inten_in || !prog_dev || !tan_dev || !dtheta) return RTT_E_NULL;
-  if (n < 0 || ld_in < n || n_theta < 2 || n_theta > 8 || (n_theta & 1)) return RTT_E_SIZE;
+  int rc = check_tangent_args(pos_in, dir_in, inten_in, ld_in, n, prog_dev, prog_host, n_surf, tan_dev, n_theta, dtheta);
+  if (rc != RTT_OK) return rc;
   if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
   if (adj_sens && sens_ld < n) return RTT_E_SIZE;
-  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(tan_dev) || misaligned(adj_pos) ||
-      misaligned(adj_dir) || misaligned(adj_sens) || (reinterpret_cast<uintptr_t>(dtheta) & 7u))
-    return RTT_E_ALIGN;
-  bool any_sensor;
-  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
-  if (rc != RTT_OK) return rc;
+  if (misaligned(adj_pos) || misaligned(adj_dir) || misaligned(adj_sens)) return RTT_E_ALIGN;
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
-  TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta};
-  const hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(grid_for_reduction(n)), block(kBlock);
-  switch (n_theta) {
-    case 2: hipLaunchKernelGGL(k_trace_seq_tangent<2>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-    case 4: hipLaunchKernelGGL(k_trace_seq_tangent<4>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-    case 6: hipLaunchKernelGGL(k_trace_seq_tangent<6>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-    default: hipLaunchKernelGGL(k_trace_seq_tangent<8>, grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-  }
-  return launch_status();
+  TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta, -1, 0.0f, 0.0f, 0.0f};
+  return launch_tangent<false>(io, prog_dev, n_surf, tio, n_theta, (hipStream_t)stream);
+}
+
+int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                                const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                                const float* tan_dev, int n_theta, int sensor_slot, double cx, double cy, double wsum,
+                                double* out, void* stream) {
+  int rc = check_tangent_args(pos_in, dir_in, inten_in, ld_in, n, prog_dev, prog_host, n_surf, tan_dev, n_theta, out);
+  if (rc != RTT_OK) return rc;
+  if (sensor_slot < 0 || sensor_slot >= RTT_MAX_SURFACES || !(wsum > 0.0)) return RTT_E_SIZE;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
+  TangentIO tio = {tan_dev, nullptr, nullptr, 0, nullptr, 0, out, sensor_slot, (float)cx, (float)cy, (float)(1.0 / wsum)};
+  return launch_tangent<true>(io, prog_dev, n_surf, tio, n_theta, (hipStream_t)stream);
 }
 
 int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, const RttSurface* prog_dev,

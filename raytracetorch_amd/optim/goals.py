@@ -50,6 +50,33 @@ class SpotSizeLoss(Goal):
                 target_xy = target_xy.unsqueeze(0).expand(len(bundles), 2)
         self._target_xy = target_xy
 
+    def _fused(self, scene, rays, tgt):
+        """Trainable sequential scene whose sensor is visited once: trace without a graph and attach the
+        single fused backward.  Returns the loss, False when nothing lit reached the sensor, or None when
+        the fused form does not apply."""
+        from .. import autograd as AG
+        from .. import kernels as K
+        from .. import program as P
+        from ..rays.ray import Rays
+        if not AG.needs_grad(scene.elements):
+            return None
+        prog = scene._program()
+        slots = [int(r["sensor_slot"]) for r in prog if int(r["sensor_slot"]) >= 0
+                 and scene.elements[int(r["element_id"])] is self.sensor]
+        if len(slots) != 1 or P.n_sensor_slots(prog) != 1:
+            return None
+        src = Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id, rays.wavelength)
+        out = Rays.from_planes(torch.empty_like(src._pos), torch.empty_like(src._dir), torch.empty_like(src.intensity),
+                               rays.id, rays.wavelength)
+        hit, w, mask = K.trace_sequential(src, prog, out=out)
+        scene._deliver_sensor_records(prog, src, hit, w, mask)
+        rays._pos, rays._dir, rays.intensity = out._pos, out._dir, out.intensity
+        k = slots[0]
+        if not bool(((w[k] > 0) & mask[k].bool()).any()):
+            return False
+        return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
+                                  group=getattr(scene, "grad_group", None))
+
     def _sensor_records(self):
         s = self.sensor
         recs = [(hit[0], hit[1], w, mask) for hit, w, mask, _ in s._dense]
@@ -68,7 +95,15 @@ class SpotSizeLoss(Goal):
                 dev = torch.device("cuda", torch.cuda.current_device())
             rays = rays.to(dev)
             scene.rays = rays
+            tgt = None
+            if self._target_xy is not None:
+                tgt = self._target_xy[min(i, self._target_xy.shape[0] - 1)]
             if isinstance(scene, SequentialScene):
+                fused = self._fused(scene, rays, tgt)
+                if fused is not None:
+                    if fused is not False:
+                        losses.append(fused)
+                    continue
                 scene.simulate(rays)   # the reference's no-argument call only works on Scene
             else:
                 scene.simulate()
@@ -76,9 +111,6 @@ class SpotSizeLoss(Goal):
             if not recs:
                 r = scene.rays
                 recs = [(r._pos[0], r._pos[1], r.intensity, None)]
-            tgt = None
-            if self._target_xy is not None:
-                tgt = self._target_xy[min(i, self._target_xy.shape[0] - 1)]
             if not bool(torch.stack([((r[2] > 0) if r[3] is None else ((r[2] > 0) & r[3].bool())).any() for r in recs]).any()):
                 continue  # nothing lit reached the sensor (optim/goals.py:165-167)
             loss = spot_size_from_records(recs, tgt, group=getattr(scene, "grad_group", None))

@@ -24,8 +24,11 @@ class SequentialScene(Scene):
         prog = self._program()
         from .. import autograd as AG
         if AG.needs_grad(self.elements):
-            # differentiable w.r.t. the scene parameters: the backward re-traces the (saved) input bundle
-            saved = rays.clone()
+            # differentiable w.r.t. the scene parameters: the backward re-traces the input bundle, whose
+            # planes stay untouched because the result goes into new tensors (nothing is written in place)
+            from ..rays.ray import Rays
+            saved = Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id,
+                                     rays.wavelength)
             pos, d, inten, sens_hit, sens_w, sens_mask = AG.trace_sequential_with_grad(
                 list(self.elements), saved, prog, group=getattr(self, "grad_group", None))
             dst = rays if out is None else out

@@ -136,3 +136,33 @@ def test_no_grad_path_is_untouched(ns):
     with torch.no_grad():
         out = ns.SequentialScene([lens, sensor]).simulate(rays)
     assert out is rays and not out._pos.requires_grad
+
+
+def test_generic_and_fused_backward_agree(ns):
+    """The fused spot-loss backward equals the composition trace-function -> loss-function (adjoint arrays
+    through HBM), for the centroid and for a fixed target."""
+    from raytracetorch_amd.optim.goals import spot_size_from_records
+    for target in (None, torch.tensor([0.1, -0.05])):
+        grads = []
+        for fused in (True, False):
+            torch.manual_seed(0)
+            lens, sensor = scenes.spot_system(ns, grads=True)
+            scene = ns.SequentialScene([lens, sensor])
+            rays = scenes.disk_bundle(ns).sample(20000).to(DEV)
+            if fused:
+                class One(torch.nn.Module):
+                    def sample(self, n):
+                        return rays
+                loss = ns.SpotSizeLoss(sensor, [One()], N_rays=20000, target_xy=target)(scene)
+            else:
+                scene.simulate(rays)
+                hit, w, mask, _ = sensor._dense[0]
+                assert hit.requires_grad
+                loss = spot_size_from_records([(hit[0], hit[1], w, mask)], target)
+            loss.backward()
+            s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+            grads.append((float(loss), [float(s0.c.grad), float(s1.c.grad), float(s0.transform.trans.grad[2]),
+                                        float(s1.transform.trans.grad[2]), float(lens.ior_glass.grad)]))
+        assert rel(grads[0][0], grads[1][0]) < 1e-6
+        for a, b in zip(grads[0][1], grads[1][1]):
+            assert rel(a, b) < 2e-4, (target, grads)
