@@ -177,7 +177,7 @@ int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float*
 int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n,
                          int pass, double cx, double cy, double wsum, double* out, void* stream);
 
-/* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1 or 2);
+/* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1, 2 or 4);
  * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride).
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);

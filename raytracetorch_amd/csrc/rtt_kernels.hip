@@ -774,22 +774,38 @@ DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, int64_t i, int nv)
 // bundle, goes through the same packed arithmetic, so a ray's result does not depend on the size or
 // alignment of the batch it is traced in.
 // ------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int G>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                       Ops ops, SensorIO se, int vec) {
+  // G groups of N rays per lane: group g of a lane sits kBlock*N rays after group g-1, so every access of
+  // a wavefront stays contiguous; the G independent instruction streams share the scalar work of a visit
+  // and fill each other's latency and hazard slots.
   constexpr int N = LaneOf<T>::N;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
-  const int64_t stride = (int64_t)gridDim.x * kBlock * N;
-  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < io.n; i += stride) {
-    const int nv = (io.n - i) >= N ? N : 1;
-    Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
+  const int64_t tile = (int64_t)kBlock * N * G;
+  const int64_t stride = (int64_t)gridDim.x * tile;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < io.n; base += stride) {
+    Ray<T> r[G];
+    int64_t idx[G];
+    int nv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      idx[g] = base + ((int64_t)g * kBlock + threadIdx.x) * N;
+      const int64_t left = io.n - idx[g];
+      nv[g] = left >= N ? N : (left >= 1 ? 1 : 0);
+      // lanes past the end (nv == 0) trace a copy of the bundle's first ray and store nothing
+      r[g] = load_ray<T>(io, nv[g] ? idx[g] : 0, vec != 0 && nv[g] == N, nv[g] ? nv[g] : 1);
+    }
     for (int s = 0; s < n_surf; ++s) {
       const RecF S{prog[s]};
-#define RTT_CALL(CFG) visit_seq<CFG>(S, r, se, i, nv)
+#define RTT_CALL(CFG)                                              \
+  _Pragma("unroll") for (int g = 0; g < G; ++g) visit_seq<CFG>(S, r[g], se, idx[g], nv[g])
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     }
-    store_ray<T>(io, i, r, vec != 0, nv);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (nv[g]) store_ray<T>(io, idx[g], r[g], vec != 0, nv[g]);
   }
 }
 
@@ -1282,9 +1298,11 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
   if (g_rays_per_lane == 1)
-    hipLaunchKernelGGL(k_trace_seq<float>, dim3(grid_for(n, 1)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, 0);
+    hipLaunchKernelGGL((k_trace_seq<float, 1>), dim3(grid_for(n, 1)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, 0);
+  else if (g_rays_per_lane == 4)
+    hipLaunchKernelGGL((k_trace_seq<f2, 2>), dim3(grid_for(n, 4)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
   else
-    hipLaunchKernelGGL(k_trace_seq<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
+    hipLaunchKernelGGL((k_trace_seq<f2, 1>), dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
   return launch_status();
 }
 
@@ -1463,7 +1481,7 @@ const char* rtt_strerror(int code) {
 int rtt_abi_version(void) { return RTT_ABI_VERSION; }
 
 int rtt_tune(int key, int value) {
-  if (key == 0 && (value == 1 || value == 2)) {
+  if (key == 0 && (value == 1 || value == 2 || value == 4)) {
     g_rays_per_lane = value;
     return RTT_OK;
   }
