@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "spot"],
                     help="singlet = the headline line; the others time the remaining configurations (informational)")
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
+    ap.add_argument("--tune-lds", type=int, default=-1, help="1: surface program staged in LDS (experiment)")
     ap.add_argument("--tune-blocks", type=int, default=0, help="override the grid cap for experiments")
     return ap.parse_args()
 
@@ -204,6 +205,8 @@ def main():
     from raytracetorch_amd import _native
     if a.tune_rpt:
         _native.check(_native.lib().rtt_tune(0, a.tune_rpt), "rtt_tune")
+    if a.tune_lds >= 0:
+        _native.check(_native.lib().rtt_tune(2, a.tune_lds), "rtt_tune")
     if a.tune_blocks:
         _native.check(_native.lib().rtt_tune(1, a.tune_blocks), "rtt_tune")
 

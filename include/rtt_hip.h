@@ -178,7 +178,8 @@ int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const u
                          int pass, double cx, double cy, double wsum, double* out, void* stream);
 
 /* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1, 2 or 4);
- * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride).
+ * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride);
+ * key 2: 1 stages the surface program in LDS, 0 (default) reads it with scalar loads.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

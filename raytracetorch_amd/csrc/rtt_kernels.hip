@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rtt_hip.h"
 
 namespace {
@@ -241,6 +243,20 @@ __device__ __forceinline__ int op_of(const Ops& ops, int s) { return (ops.w[s >>
 // dual numbers carrying d(field)/d(parameter)).
 struct RecF {
   const RttSurface& r;
+  DI float Rs(int i) const { return r.Rs[i]; }
+  DI float ts(int i) const { return r.ts[i]; }
+  DI float Rj(int i) const { return r.Rj[i]; }
+  DI float tj(int i) const { return r.tj[i]; }
+  DI float geom(int i) const { return r.geom[i]; }
+  DI float phys(int i) const { return r.phys[i]; }
+  DI float bnd(int i) const { return r.bnd[i]; }
+  DI float shp(int i) const { return r.shp[i]; }
+};
+
+// LDS view: the same fields read from a copy of the program staged in LDS (ds_read with a wave-uniform
+// address).  Kept as a measured alternative to the scalar-load view (rtt_tune key 2).
+struct RecL {
+  const RttSurface& r;  // LDS-resident record
   DI float Rs(int i) const { return r.Rs[i]; }
   DI float ts(int i) const { return r.ts[i]; }
   DI float Rj(int i) const { return r.Rj[i]; }
@@ -774,9 +790,16 @@ DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, int64_t i, int nv)
 // bundle, goes through the same packed arithmetic, so a ray's result does not depend on the size or
 // alignment of the batch it is traced in.
 // ------------------------------------------------------------------------------------------------
-template <class T, int G>
+template <class T, int G, bool LDS_PROG>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                       Ops ops, SensorIO se, int vec) {
+  __shared__ RttSurface lds_prog[LDS_PROG ? RTT_MAX_SURFACES : 1];
+  if (LDS_PROG) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(prog_);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds_prog);
+    for (int w = threadIdx.x; w < n_surf * (int)(sizeof(RttSurface) / 4); w += kBlock) dst[w] = src[w];
+    __syncthreads();
+  }
   // G groups of N rays per lane: group g of a lane sits kBlock*N rays after group g-1, so every access of
   // a wavefront stays contiguous; the G independent instruction streams share the scalar work of a visit
   // and fill each other's latency and hazard slots.
@@ -797,7 +820,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
       r[g] = load_ray<T>(io, nv[g] ? idx[g] : 0, vec != 0 && nv[g] == N, nv[g] ? nv[g] : 1);
     }
     for (int s = 0; s < n_surf; ++s) {
-      const RecF S{prog[s]};
+      typename std::conditional<LDS_PROG, RecL, RecF>::type S{LDS_PROG ? lds_prog[s] : prog[s]};
 #define RTT_CALL(CFG)                                              \
   _Pragma("unroll") for (int g = 0; g < G; ++g) visit_seq<CFG>(S, r[g], se, idx[g], nv[g])
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
@@ -1193,6 +1216,7 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // tuning knobs (rtt_tune): rays carried per lane in the sequential trace, and the grid cap
 int g_rays_per_lane = 2;
+int g_program_in_lds = 0;  // 1: stage the surface program in LDS instead of reading it with scalar loads
 // One tile per block by default: blocks that finish are replaced by blocks that start with their
 // loads, which overlaps HBM latency with the arithmetic of the resident waves (measured on the 64 Mi
 // singlet trace: 0.83 ms with a 2048-block grid-stride cap, 0.77 ms uncapped).
@@ -1298,11 +1322,13 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
   if (g_rays_per_lane == 1)
-    hipLaunchKernelGGL((k_trace_seq<float, 1>), dim3(grid_for(n, 1)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, 0);
+    hipLaunchKernelGGL((k_trace_seq<float, 1, false>), dim3(grid_for(n, 1)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, 0);
   else if (g_rays_per_lane == 4)
-    hipLaunchKernelGGL((k_trace_seq<f2, 2>), dim3(grid_for(n, 4)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
+    hipLaunchKernelGGL((k_trace_seq<f2, 2, false>), dim3(grid_for(n, 4)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
+  else if (g_program_in_lds)
+    hipLaunchKernelGGL((k_trace_seq<f2, 1, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
   else
-    hipLaunchKernelGGL((k_trace_seq<f2, 1>), dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
+    hipLaunchKernelGGL((k_trace_seq<f2, 1, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
   return launch_status();
 }
 
@@ -1483,6 +1509,10 @@ int rtt_abi_version(void) { return RTT_ABI_VERSION; }
 int rtt_tune(int key, int value) {
   if (key == 0 && (value == 1 || value == 2 || value == 4)) {
     g_rays_per_lane = value;
+    return RTT_OK;
+  }
+  if (key == 2 && (value == 0 || value == 1)) {
+    g_program_in_lds = value;
     return RTT_OK;
   }
   if (key == 1 && value >= 1 && value <= (1 << 20)) {
