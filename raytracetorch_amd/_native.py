@@ -12,7 +12,8 @@ import torch
 from . import program as P
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librtt_hip.so")
+# RTT_HIP_LIB selects another build of the same ABI (the strict-fp build, an A/B candidate)
+LIB_PATH = os.environ.get("RTT_HIP_LIB") or os.path.join(_HERE, "csrc", "librtt_hip.so")
 
 _lib = None
 

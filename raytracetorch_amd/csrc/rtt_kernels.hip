@@ -45,42 +45,50 @@ constexpr bool kStrict = RTT_STRICT_FP != 0;
 // or `f2` (two rays per lane).  The f32 vector ALU of gfx950 retires a wave64 mul / add / fma in four
 // cycles whether it is scalar or packed, so carrying two rays per lane in v_pk_{mul,add,fma}_f32
 // halves the cost of most of the arithmetic; compares, selects and the transcendental units stay
-// per component.  Masks are `bool` for float and an int vector (-1 / 0 per component) for f2.
+// per component.  Masks are `bool` for float and a boolean vector for f2: a per-lane bool lives in a
+// scalar register pair (lane mask), so mask logic runs on the scalar unit and a select is one v_cndmask.
 // ------------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i2 __attribute__((ext_vector_type(2)));
+typedef bool b2 __attribute__((ext_vector_type(2)));
 
 template <class T> struct LaneOf;
 template <> struct LaneOf<float> { using M = bool; static constexpr int N = 1; };
-template <> struct LaneOf<f2> { using M = i2; static constexpr int N = 2; };
+template <> struct LaneOf<f2> { using M = b2; static constexpr int N = 2; };
 
 #define DI __device__ __forceinline__
 DI bool lt(float a, float b) { return a < b; }
-DI i2 lt(f2 a, f2 b) { return a < b; }
+DI b2 lt(f2 a, f2 b) { return __builtin_convertvector(a < b, b2); }
 DI bool le(float a, float b) { return a <= b; }
-DI i2 le(f2 a, f2 b) { return a <= b; }
+DI b2 le(f2 a, f2 b) { return __builtin_convertvector(a <= b, b2); }
 DI bool ge(float a, float b) { return a >= b; }
-DI i2 ge(f2 a, f2 b) { return a >= b; }
+DI b2 ge(f2 a, f2 b) { return __builtin_convertvector(a >= b, b2); }
 DI bool gt(float a, float b) { return a > b; }
-DI i2 gt(f2 a, f2 b) { return a > b; }
+DI b2 gt(f2 a, f2 b) { return __builtin_convertvector(a > b, b2); }
 DI bool isnan_(float a) { return a != a; }
-DI i2 isnan_(f2 a) { return a != a; }
-DI bool and_(bool a, bool b) { return a && b; }
-DI i2 and_(i2 a, i2 b) { return a & b; }
-DI bool or_(bool a, bool b) { return a || b; }
-DI i2 or_(i2 a, i2 b) { return a | b; }
+DI b2 isnan_(f2 a) { return __builtin_convertvector(a != a, b2); }
+DI bool and_(bool a, bool b) { return a & b; }
+DI b2 and_(b2 a, b2 b) { return a & b; }
+DI bool or_(bool a, bool b) { return a | b; }
+DI b2 or_(b2 a, b2 b) { return a | b; }
 DI bool not_(bool a) { return !a; }
-DI i2 not_(i2 a) { return ~a; }
+DI b2 not_(b2 a) { return ~a; }
 DI bool any_(bool a) { return a; }
-DI bool any_(i2 a) { return (a.x | a.y) != 0; }
+DI bool any_(b2 a) { return a[0] | a[1]; }
+DI bool all_(bool a) { return a; }
+DI bool all_(b2 a) { return a[0] & a[1]; }
+template <class M> DI M mask_all(bool v);
+template <> DI bool mask_all<bool>(bool v) { return v; }
+template <> DI b2 mask_all<b2>(bool v) { return b2{v, v}; }
 DI float sel(bool m, float a, float b) { return m ? a : b; }
-DI f2 sel(i2 m, f2 a, f2 b) { return m ? a : b; }
+DI f2 sel(b2 m, f2 a, f2 b) { return f2{m[0] ? a.x : b.x, m[1] ? a.y : b.y}; }
 DI float abs_(float a) { return fabsf(a); }
 DI f2 abs_(f2 a) { return __builtin_elementwise_abs(a); }
 DI float max_(float a, float b) { return fmaxf(a, b); }
 DI f2 max_(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
-DI float min_(float a, float b) { return fminf(a, b); }
-DI f2 min_(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+// min of two values that are not NaN (callers guarantee it): compare + select, no canonicalisation
+DI float min_(float a, float b) { return a < b ? a : b; }
+DI f2 min_(f2 a, f2 b) { return f2{a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y}; }
 DI float sqrt_ieee(float a) { return sqrtf(a); }
 DI f2 sqrt_ieee(f2 a) { return f2{sqrtf(a.x), sqrtf(a.y)}; }
 DI float div_ieee(float a, float b) { return a / b; }
@@ -108,7 +116,7 @@ template <class T> DI T splat(float v) { return T(v); }
 DI float comp(float a, int) { return a; }
 DI float comp(f2 a, int k) { return k == 0 ? a.x : a.y; }
 DI bool mcomp(bool m, int) { return m; }
-DI bool mcomp(i2 m, int k) { return (k == 0 ? m.x : m.y) != 0; }
+DI bool mcomp(b2 m, int k) { return k == 0 ? m[0] : m[1]; }
 
 
 // ------------------------------------------------------------------------------------------------
@@ -185,8 +193,10 @@ template <class T, class M> DI V3<T> sel3(M m, V3<T> a, V3<T> b) { return {sel(m
 // ------------------------------------------------------------------------------------------------
 constexpr int DYN = -1;
 
-template <int SK, int BK, int HK, int PK, bool ROT_ID>
+template <int SK, int BK, int HK, int PK, bool ROT_ID, int INV = 0>
 struct Cfg {
+  // SurfaceBounded.invert: read from the record (INV == DYN) or known to be clear (INV == 0)
+  static __device__ __forceinline__ bool inv(const RttSurface& S) { return INV == DYN ? (S.flags & RTT_F_INVERT) != 0 : false; }
   static __device__ __forceinline__ int sk(const RttSurface& S) { return SK == DYN ? S.surf_kind : SK; }
   static __device__ __forceinline__ int bk(const RttSurface& S) { return BK == DYN ? S.bound_kind : BK; }
   static __device__ __forceinline__ int hk(const RttSurface& S) { return HK == DYN ? S.shape_kind : HK; }
@@ -202,14 +212,14 @@ struct Cfg {
   }
 };
 
-using CGeneric = Cfg<DYN, DYN, DYN, DYN, false>;
+using CGeneric = Cfg<DYN, DYN, DYN, DYN, false, DYN>;
 // spherical / conic lens face of a Spheric stack, unrotated element, Snell refraction
 using CFaceSnell = Cfg<RTT_SURF_QUADRIC, RTT_BND_HALF, RTT_SHP_SPHERIC_FACE, RTT_PHYS_SNELL, true>;
 // cylindrical lens edge of a Spheric stack, inked (Block) or clear (Snell)
 using CEdgeBlock = Cfg<RTT_SURF_CYLINDER, RTT_BND_NONE, RTT_SHP_SPHERIC_EDGE, RTT_PHYS_BLOCK, true>;
 using CEdgeSnell = Cfg<RTT_SURF_CYLINDER, RTT_BND_NONE, RTT_SHP_SPHERIC_EDGE, RTT_PHYS_SNELL, true>;
 // bare disk-bounded plane: sensors (Transmit) and circular stops (ApertureFilter)
-using CDiskPlane = Cfg<RTT_SURF_PLANE, RTT_BND_DISK, RTT_SHP_NONE, DYN, true>;
+using CDiskPlane = Cfg<RTT_SURF_PLANE, RTT_BND_DISK, RTT_SHP_NONE, DYN, true, DYN>;
 // bare spherical mirror cap
 using CMirrorCap = Cfg<RTT_SURF_QUADRIC, RTT_BND_HALF_DISK, RTT_SHP_NONE, RTT_PHYS_REFLECT, true>;
 // cylindrical lens: curved faces (unrotated) and the four side planes (rotated by +-90 degrees)
@@ -319,7 +329,8 @@ DI V3<T> rowmat_t(V3<T> v, const RV& S, bool ident) {
 // torch.min over a stacked dim propagates NaN (geom/primitives.py:34, geom/bounded.py:34)
 template <class T>
 DI T nanmin(T a, T b) {
-  return sel(or_(isnan_(a), isnan_(b)), splat<T>(__builtin_nanf("")), min_(a, b));
+  // a when a < b or a is NaN, else b (which is the smaller value or itself NaN)
+  return sel(or_(lt(a, b), isnan_(a)), a, b);
 }
 
 template <class T>
@@ -401,7 +412,7 @@ DI int solve_roots(const RV& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
       const T safe = sel(lt(abs_(d.z), splat<T>(kEps)), splat<T>(1e-8f), d.z);
       t1 = quot(-o.z, safe);
       t2 = t1;
-      ok = ge(splat<T>(1.0f), zero);
+      ok = mask_all<M>(true);
       return 1;
     }
     case RTT_SURF_SPHERE: {  // geom/primitives.py:155-181
@@ -478,36 +489,58 @@ DI typename LaneOf<T>::M surface_in_bounds(const RV& S, V3<T> h) {
     case RTT_BND_SINGLE_CONE:  // bounded.py:208-217
       return ge(h.z * S.geom(0), splat<T>(-kEps));
     default:  // RTT_BND_ALWAYS
-      return ge(splat<T>(1.0f), splat<T>(0.0f));
+      return mask_all<typename LaneOf<T>::M>(true);
   }
 }
 
-// Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36).
-// `ok` false stands for a root the reference has already replaced by inf: inf fails neither the
-// epsilon test nor (as a NaN hit point) an un-inverted bound, so it stays inf there as here.
+// Surface._check_t (geom/primitives.py:28-36) / SurfaceBounded._check_t (geom/bounded.py:20-36) for one
+// root: true when the reference keeps the root, false when it replaces it by inf.  `ok` false stands
+// for a root the reference has already set to inf: inf fails neither the epsilon test nor (as a NaN hit
+// point) an un-inverted bound, so it stays inf there as here.
 template <class C, class RV, class T, class M>
-DI T filter_root(const RV& S, const Frames<T>& f, T r, M ok) {
-  auto bad = or_(not_(ok), le(r, splat<T>(kEps)));
+DI M root_kept(const RV& S, const Frames<T>& f, T r, M ok) {
+  M good = and_(ok, not_(le(r, splat<T>(kEps))));
   if (C::bk(S.r) != RTT_BND_NONE) {
     V3<T> h = f.pl + scale(r, f.dl);
     auto keep = surface_in_bounds<C>(S, h);
-    if (S.r.flags & RTT_F_INVERT) keep = not_(keep);
-    bad = or_(bad, not_(keep));
+    if (C::inv(S.r)) keep = not_(keep);
+    good = and_(good, keep);
   }
-  return sel(bad, splat<T>(kInf), r);
+  return good;
+}
+
+// min over the filtered roots (geom/primitives.py:34, geom/bounded.py:34): the column value t (inf on
+// a miss) and `finite` = t < inf.
+template <class C, class RV, class T, class M>
+DI T solve_t(const RV& S, const Frames<T>& f, M& finite) {
+  T t1, t2;
+  M ok;
+  const T inf = splat<T>(kInf);
+  const int n = solve_roots<C>(S, f.pl, f.dl, t1, t2, ok);
+  const M g1 = root_kept<C>(S, f, t1, ok);
+  if (n == 1) {
+    const T t = sel(g1, t1, inf);
+    finite = lt(t, inf);
+    return t;
+  }
+  const M g2 = root_kept<C>(S, f, t2, ok);
+  const int bk = C::bk(S.r);
+  if (bk != RTT_BND_NONE && bk != RTT_BND_ALWAYS && !C::inv(S.r)) {
+    // a kept root passed a bound test on its hit point, so it is finite and not NaN: choose on the masks
+    const M first = and_(g1, or_(not_(g2), lt(t1, t2)));
+    finite = or_(g1, g2);
+    return sel(finite, sel(first, t1, t2), inf);
+  }
+  // unbounded surfaces and inverted bounds can keep a NaN root; torch.min propagates it
+  const T t = nanmin(sel(g1, t1, inf), sel(g2, t2, inf));
+  finite = lt(t, inf);
+  return t;
 }
 
 template <class C, class RV, class T>
 DI T solve_t(const RV& S, const Frames<T>& f) {
-  T t1, t2;
-  typename LaneOf<T>::M ok;
-  const int n = solve_roots<C>(S, f.pl, f.dl, t1, t2, ok);
-  t1 = filter_root<C>(S, f, t1, ok);
-  if (n == 1) return t1;
-  t2 = filter_root<C>(S, f, t2, ok);
-  // a NaN root survives only on unbounded surfaces or inverted bounds (a NaN hit point is out of bounds)
-  if (C::bk(S.r) != RTT_BND_NONE && !(S.r.flags & RTT_F_INVERT)) return min_(t1, t2);
-  return nanmin(t1, t2);
+  typename LaneOf<T>::M finite;
+  return solve_t<C>(S, f, finite);
 }
 
 // HalfCyl.sagittalZ with a per-ray height (geom/bounded.py:176-186)
@@ -538,7 +571,7 @@ DI typename LaneOf<T>::M shape_in_bounds(const RV& S, V3<T> h) {
       return and_(and_(ge(h.z, zf + 1e-4f), le(h.z, zb - 1e-4f)), ap);
     }
     default:
-      return ge(splat<T>(1.0f), splat<T>(0.0f));
+      return mask_all<typename LaneOf<T>::M>(true);
   }
 }
 
@@ -548,8 +581,8 @@ DI typename LaneOf<T>::M shape_in_bounds(const RV& S, V3<T> h) {
 template <class C, class RV, class T>
 DI typename LaneOf<T>::M test_surface(const RV& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
   f = to_frames<C>(S, p, d);
-  t_raw = solve_t<C>(S, f);
-  auto valid = lt(t_raw, splat<T>(kInf));
+  typename LaneOf<T>::M valid;
+  t_raw = solve_t<C>(S, f, valid);
   if (C::has_shape(S.r)) {
     V3<T> he = f.pe + scale(t_raw, f.de);
     valid = and_(valid, shape_in_bounds<C>(S, he));
@@ -762,7 +795,7 @@ DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, con
   T im;
   apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im);
   if (sensor) record_sensor(se, S.r.sensor_slot, i, hit, fw.hit_l, r.I, nv);
-  if (__all(!any_(not_(hit)))) {  // every ray of the wavefront hits: plain moves, no selects
+  if (__all(all_(hit))) {  // every ray of the wavefront hits: plain moves, no selects
     r.p = fw.hit_g;
     r.d = nd;
     r.I = r.I * im;
@@ -951,7 +984,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
 // Every ray tests every surface, so the cast runs on packed lanes (two rays per lane) like the
 // sequential trace; `win` is an int per component.
 DI int isel(bool m, int a, int b) { return m ? a : b; }
-DI i2 isel(i2 m, int a, i2 b) { return m ? i2(a) : b; }
+DI i2 isel(b2 m, int a, i2 b) { return i2{m[0] ? a : b.x, m[1] ? a : b.y}; }
 template <class T> struct WinOf { using type = int; };
 template <> struct WinOf<f2> { using type = i2; };
 DI int icomp(int a, int) { return a; }
