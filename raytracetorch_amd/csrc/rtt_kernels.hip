@@ -582,6 +582,19 @@ template <class C, class RV, class T>
 DI typename LaneOf<T>::M test_surface(const RV& S, V3<T> p, V3<T> d, Frames<T>& f, T& t_raw) {
   f = to_frames<C>(S, p, d);
   typename LaneOf<T>::M valid;
+  if (C::hk(S.r) == RTT_SHP_SPHERIC_EDGE) {
+    // Slab rejection for lens edges: a kept root has t > 0, so the element-frame hit height
+    // pe.z + t de.z lies beyond pe.z in the direction of de.z; a ray already past the edge's z range and
+    // moving away cannot land inside it.  When that holds for every ray of the wavefront the quadratic
+    // is skipped; the result (a miss) is exactly what the full evaluation returns.
+    const T zero = splat<T>(0.0f);
+    const auto away = or_(and_(ge(f.de.z, zero), gt(f.pe.z, splat<T>(S.shp(1)))),
+                          and_(le(f.de.z, zero), lt(f.pe.z, splat<T>(S.shp(0)))));
+    if (__all(all_(away))) {
+      t_raw = splat<T>(kInf);
+      return mask_all<typename LaneOf<T>::M>(false);
+    }
+  }
   t_raw = solve_t<C>(S, f, valid);
   if (C::has_shape(S.r)) {
     V3<T> he = f.pe + scale(t_raw, f.de);
@@ -728,13 +741,15 @@ struct Ray {
 // Lane type T at ray index i: float reads ray i; f2 reads rays i and i+1, with one 8-byte access when
 // `vec` (planes 8-byte aligned) and both rays exist, else with two 4-byte accesses; a lane holding only
 // the last ray of an odd-length bundle (nv == 1) duplicates it into its second component.
-DI float ld_(const float* p, int64_t i, bool, int, float*) { return p[i]; }
-DI f2 ld_(const float* p, int64_t i, bool vec, int nv, f2*) {
+// The index type I is int64_t for absolute ray indices or uint32_t for offsets from a wave-uniform base
+// pointer (a 32-bit lane offset lets the load take its base from scalar registers, no 64-bit address math).
+template <class I> DI float ld_(const float* p, I i, bool, int, float*) { return p[i]; }
+template <class I> DI f2 ld_(const float* p, I i, bool vec, int nv, f2*) {
   if (vec && nv == 2) return *reinterpret_cast<const f2*>(p + i);
   return f2{p[i], p[i + (nv - 1)]};
 }
-DI void st_(float* p, int64_t i, float v, bool, int) { p[i] = v; }
-DI void st_(float* p, int64_t i, f2 v, bool vec, int nv) {
+template <class I> DI void st_(float* p, I i, float v, bool, int) { p[i] = v; }
+template <class I> DI void st_(float* p, I i, f2 v, bool vec, int nv) {
   if (vec && nv == 2) {
     *reinterpret_cast<f2*>(p + i) = v;
   } else {
@@ -743,8 +758,8 @@ DI void st_(float* p, int64_t i, f2 v, bool vec, int nv) {
   }
 }
 
-template <class T>
-DI Ray<T> load_ray(const RayIO& io, int64_t i, bool vec = false, int nv = LaneOf<T>::N) {
+template <class T, class I>
+DI Ray<T> load_ray(const RayIO& io, I i, bool vec = false, int nv = LaneOf<T>::N) {
   Ray<T> r;
   T* tag = nullptr;
   r.p = {ld_(io.pos_in, i, vec, nv, tag), ld_(io.pos_in + io.ld_in, i, vec, nv, tag),
@@ -755,8 +770,8 @@ DI Ray<T> load_ray(const RayIO& io, int64_t i, bool vec = false, int nv = LaneOf
   return r;
 }
 
-template <class T>
-DI void store_ray(const RayIO& io, int64_t i, const Ray<T>& r, bool vec = false, int nv = LaneOf<T>::N) {
+template <class T, class I>
+DI void store_ray(const RayIO& io, I i, const Ray<T>& r, bool vec = false, int nv = LaneOf<T>::N) {
   st_(io.pos_out, i, r.p.x, vec, nv);
   st_(io.pos_out + io.ld_out, i, r.p.y, vec, nv);
   st_(io.pos_out + 2 * io.ld_out, i, r.p.z, vec, nv);
@@ -766,27 +781,32 @@ DI void store_ray(const RayIO& io, int64_t i, const Ray<T>& r, bool vec = false,
   st_(io.inten_out, i, r.I, vec, nv);
 }
 
-template <class T, class M>
-DI void record_sensor(const SensorIO& se, int slot, int64_t i, M hit, V3<T> hl, T I, int nv) {
-  const int64_t base = (int64_t)slot * se.ld;
+template <class T, class M, class IX>
+DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, int nv) {
+  const int64_t base = (int64_t)slot * se.ld;  // wave-uniform: the slot's planes are addressed by pointer
+  uint8_t* mask = se.mask + base;
+  float* hx = se.hit + 3 * base;
+  float* hy = hx + se.ld;
+  float* hz = hy + se.ld;
+  float* w = se.w + base;
 #pragma unroll
   for (int k = 0; k < LaneOf<T>::N; ++k) {
     if (k >= nv) break;
     const bool h = mcomp(hit, k);
-    se.mask[base + i + k] = h ? 1 : 0;
+    mask[i + k] = h ? 1 : 0;
     if (h) {
-      se.hit[(3 * base) + i + k] = comp(hl.x, k);
-      se.hit[(3 * base) + se.ld + i + k] = comp(hl.y, k);
-      se.hit[(3 * base) + 2 * se.ld + i + k] = comp(hl.z, k);
-      se.w[base + i + k] = comp(I, k);
+      hx[i + k] = comp(hl.x, k);
+      hy[i + k] = comp(hl.y, k);
+      hz[i + k] = comp(hl.z, k);
+      w[i + k] = comp(I, k);
     }
   }
 }
 
 // Apply surface S to the ray(s) of a lane where hit: Element.forward + Rays.scatter_update
 // (elements/parent.py:44-58, rays/ray.py:29-40, elements/sensor.py:35-37).
-template <class C, class RV, class T, class M>
-DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, int64_t i,
+template <class C, class RV, class T, class M, class I>
+DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, const SensorIO& se, I i,
                  int nv = LaneOf<T>::N) {
   const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
   if (!sensor && !any_(hit)) return;  // lanes without a hit are done; a wavefront without hits skips the block
@@ -807,8 +827,8 @@ DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, con
 }
 
 // test + interact of one surface (scene/sequential.py:19-34)
-template <class C, class RV, class T>
-DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, int64_t i, int nv) {
+template <class C, class RV, class T, class I>
+DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, I i, int nv) {
   Frames<T> f;
   T t_raw;
   const auto hit = test_surface<C>(S, r.p, r.d, f, t_raw);
@@ -841,27 +861,47 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
   const int64_t tile = (int64_t)kBlock * N * G;
   const int64_t stride = (int64_t)gridDim.x * tile;
   for (int64_t base = (int64_t)blockIdx.x * tile; base < io.n; base += stride) {
+    // the tile's planes are addressed from wave-uniform base pointers with 32-bit lane offsets
+    const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in,
+                       io.pos_out + base, io.dir_out + base, io.inten_out + base, io.ld_out, io.n - base};
+    const SensorIO tse = {se.hit ? se.hit + base : nullptr, se.w ? se.w + base : nullptr,
+                          se.mask ? se.mask + base : nullptr, se.ld};
     Ray<T> r[G];
-    int64_t idx[G];
+    uint32_t idx[G];
     int nv[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      idx[g] = base + ((int64_t)g * kBlock + threadIdx.x) * N;
-      const int64_t left = io.n - idx[g];
+      idx[g] = ((uint32_t)g * kBlock + threadIdx.x) * N;
+      const int64_t left = tio.n - (int64_t)idx[g];
       nv[g] = left >= N ? N : (left >= 1 ? 1 : 0);
-      // lanes past the end (nv == 0) trace a copy of the bundle's first ray and store nothing
-      r[g] = load_ray<T>(io, nv[g] ? idx[g] : 0, vec != 0 && nv[g] == N, nv[g] ? nv[g] : 1);
+    }
+    // a full tile of aligned planes (wave-uniform condition) moves with one N*4-byte access per lane and
+    // plane; the last tile of a bundle and unaligned planes take the general path
+    const bool whole = vec != 0 && tio.n >= tile;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (whole) {
+        r[g] = load_ray<T>(tio, idx[g], true, N);
+      } else {
+        // lanes past the end (nv == 0) trace a copy of the tile's first ray and store nothing
+        r[g] = load_ray<T>(tio, nv[g] ? idx[g] : 0u, vec != 0 && nv[g] == N, nv[g] ? nv[g] : 1);
+      }
     }
     for (int s = 0; s < n_surf; ++s) {
       typename std::conditional<LDS_PROG, RecL, RecF>::type S{LDS_PROG ? lds_prog[s] : prog[s]};
 #define RTT_CALL(CFG)                                              \
-  _Pragma("unroll") for (int g = 0; g < G; ++g) visit_seq<CFG>(S, r[g], se, idx[g], nv[g])
+  _Pragma("unroll") for (int g = 0; g < G; ++g) visit_seq<CFG>(S, r[g], tse, idx[g], nv[g])
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-      if (nv[g]) store_ray<T>(io, idx[g], r[g], vec != 0, nv[g]);
+    for (int g = 0; g < G; ++g) {
+      if (whole) {
+        store_ray<T>(tio, idx[g], r[g], true, N);
+      } else if (nv[g]) {
+        store_ray<T>(tio, idx[g], r[g], vec != 0, nv[g]);
+      }
+    }
   }
 }
 
