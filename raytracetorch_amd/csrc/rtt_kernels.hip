@@ -39,6 +39,10 @@ constexpr int kBlock = 256;
 #define RTT_STRICT_FP 0
 #endif
 constexpr bool kStrict = RTT_STRICT_FP != 0;
+// Ray planes are streamed once per launch: non-temporal accesses keep them from displacing each other in L2
+#ifndef RTT_NONTEMPORAL
+#define RTT_NONTEMPORAL 1
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Lane types.  All per-ray arithmetic is written once over a lane type T: `float` (one ray per lane)
@@ -745,13 +749,13 @@ struct Ray {
 // pointer (a 32-bit lane offset lets the load take its base from scalar registers, no 64-bit address math).
 template <class I> DI float ld_(const float* p, I i, bool, int, float*) { return p[i]; }
 template <class I> DI f2 ld_(const float* p, I i, bool vec, int nv, f2*) {
-  if (vec && nv == 2) return *reinterpret_cast<const f2*>(p + i);
+  if (vec && nv == 2) return RTT_NONTEMPORAL ? __builtin_nontemporal_load(reinterpret_cast<const f2*>(p + i)) : *reinterpret_cast<const f2*>(p + i);
   return f2{p[i], p[i + (nv - 1)]};
 }
 template <class I> DI void st_(float* p, I i, float v, bool, int) { p[i] = v; }
 template <class I> DI void st_(float* p, I i, f2 v, bool vec, int nv) {
   if (vec && nv == 2) {
-    *reinterpret_cast<f2*>(p + i) = v;
+    if (RTT_NONTEMPORAL) __builtin_nontemporal_store(v, reinterpret_cast<f2*>(p + i)); else *reinterpret_cast<f2*>(p + i) = v;
   } else {
     p[i] = v.x;
     if (nv == 2) p[i + 1] = v.y;
