@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=64 * 2 ** 20, help="rays per GPU")
     ap.add_argument("--cpu-rays", type=int, default=2 ** 24, help="rays of the CPU-baseline sample (about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "spot"],
+    ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "spot", "sample_trace"],
                     help="singlet = the headline line; the others time the remaining configurations (informational)")
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
     ap.add_argument("--tune-lds", type=int, default=-1, help="1: surface program staged in LDS (experiment)")
@@ -44,9 +44,16 @@ def parse():
     return ap.parse_args()
 
 
-def device_bundle(n, device, seed):
-    """CollimatedDisk(radius=4) at z=-30 along +z, generated on the device as [3,N] planes."""
+def device_bundle(n, device, seed, offset=0, ns=None):
+    """CollimatedDisk(radius=4) at z=-30 along +z as [3,N] planes.  On a HIP device the rays come from the
+    product's device sampler (Philox stream `seed`, global ray indices offset .. offset+n-1, so the shards of
+    all ranks form one bundle); the CPU sample for the baseline uses torch ops."""
     import math
+    if ns is not None and torch.device(device).type == "cuda":
+        b = ns.CollimatedDisk(radius=4.0, ray_id=0, device=device,
+                              transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(device))
+        r = b.sample(n, offset=offset, seed=seed)
+        return r._pos, r._dir
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     theta = torch.rand(n, device=device, generator=g) * (2 * math.pi)
@@ -99,9 +106,9 @@ def cpu_baseline(n, scenes, ns):
 def other_workload(a, ns, scenes, dev, rank, world, dist):
     """Configurations 3-5: 5-element system (16 Mi rays), 32-surface nearest-hit step (4 Mi rays), spot-size
     loss forward+backward (singlet + sensor).  Same timing discipline as the headline line."""
-    defaults = {"system5": 16 * 2 ** 20, "naive32": 4 * 2 ** 20, "spot": 32 * 2 ** 20}
+    defaults = {"system5": 16 * 2 ** 20, "naive32": 4 * 2 ** 20, "spot": 32 * 2 ** 20, "sample_trace": 64 * 2 ** 20}
     n = a.rays if a.rays != 64 * 2 ** 20 else defaults[a.workload]
-    pos, d = device_bundle(n, dev, 1000 + rank)
+    pos, d = device_bundle(n, dev, 1000, offset=rank * n, ns=ns)
     mk = lambda p, q: ns.Rays.from_planes(p, q, torch.ones(n, device=dev), torch.zeros(n, device=dev, dtype=torch.int8),
                                           torch.zeros(n, device=dev))
     rays = mk(pos, d)
@@ -116,6 +123,18 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
             elements[-1].reset()
             scene.simulate(rays, out=out)
         bytes_per_ray = 56 + 1 + 17  # state in/out + sensor mask + (upper bound) one recorded hit
+    elif a.workload == "sample_trace":
+        # end to end: CollimatedDisk.sample(n) on the device (write-only kernel) + in-place singlet trace
+        scene = ns.SequentialScene([scenes.singlet(ns)])
+        bundle = ns.CollimatedDisk(radius=4.0, ray_id=0, device=dev,
+                                   transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(dev))
+        surfaces = 3
+        kernel = "k_sample_bundle + k_trace_seq"
+        del rays, pos, d
+
+        def step():
+            scene.simulate(bundle.sample(n, offset=rank * n, seed=7))
+        bytes_per_ray = 33 + 56
     elif a.workload == "naive32":
         scene = ns.Scene()
         for el in scenes.naive32(ns):
@@ -217,7 +236,7 @@ def main():
 
     n = a.rays
     scene = ns.SequentialScene([scenes.singlet(ns)])
-    pos, d = device_bundle(n, dev, 1000 + rank)
+    pos, d = device_bundle(n, dev, 1000, offset=rank * n, ns=ns)
     mk = lambda p, q: ns.Rays.from_planes(p, q, torch.ones(n, device=dev), torch.zeros(n, device=dev, dtype=torch.int8),
                                           torch.zeros(n, device=dev))
     rays = mk(pos, d)

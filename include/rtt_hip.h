@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTT_ABI_VERSION 1
+#define RTT_ABI_VERSION 2
 #define RTT_MAX_SURFACES 64 /* upper bound on n_surf accepted by every entry point */
 
 /* error codes */
@@ -176,6 +176,36 @@ int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float*
  * `out` is 4 doubles in device memory that the caller zeroes before pass 0. */
 int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n,
                          int pass, double cx, double cy, double wsum, double* out, void* stream);
+
+/* ---- ray sources: Bundle.sample(N) (rays/bundle.py:30-37) generated on the device ----------------
+ * Local sample (rays/bundle.py:40-171) -> RayTransformBundle.transform_ (geom/transform.py:247-264:
+ * pos @ R^T + t, dir @ R^T) -> Rays.initialize (rays/ray.py:42-82: dir / max(|dir|, 1e-12), intensity 1,
+ * wavelength 0, id = ray_id as int8).  The reference draws its uniforms from torch.distributions.Uniform
+ * (low + rand * (high - low)); here rand comes from Philox4x32-10 keyed by `seed`: the pair of rays with
+ * global indices (2j, 2j+1) uses counter (j lo, j hi, 0, 0) and the outputs (x0, x1 | x2, x3) as its
+ * (first, second) uniform, u = (x >> 8) * 2^-24.  A ray's values depend only on (seed, global index), so
+ * shards that pass their global `offset` reproduce the single-call bundle. */
+enum {
+  RTT_SRC_PENCIL = 0, /* Bundle: pos 0, dir +z                                 rays/bundle.py:24-28   */
+  RTT_SRC_DISK = 1,   /* DiskSample: theta = U(par[2], par[3]) first, then r = sqrt(U(par[0], par[1]));
+                         pos (r cos, r sin, 0), dir +z                         rays/bundle.py:40-56,83-98 */
+  RTT_SRC_LINE = 2,   /* pos (U(par[0], par[1]), 0, 0), dir +z                 rays/bundle.py:101-118 */
+  RTT_SRC_FAN = 3,    /* theta = U(par[0], par[1]); dir (0, sin, cos)          rays/bundle.py:121-140 */
+  RTT_SRC_POINT = 4   /* phi = acos(1 - 2 U(par[0], par[1])) first, then theta = U(par[2], par[3]);
+                         dir (cos(theta) sin(phi), sin(theta) sin(phi), cos(phi)) rays/bundle.py:58-80,143-171 */
+};
+
+typedef struct RttSource {
+  int32_t kind, ray_id;
+  float par[4];
+  float R[9], t[3]; /* RayTransformBundle: rotation matrix (row-major) and translation */
+  uint64_t seed;    /* Philox key */
+  uint64_t offset;  /* global index of the first ray of this call */
+} RttSource;
+
+/* pos, dir: plane triples with leading dimension ld; inten, id, wavelength: [n], each nullable. */
+int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t ld, float* inten, int8_t* id,
+                          float* wavelength, int64_t n, void* stream);
 
 /* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1, 2 or 4);
  * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride);

@@ -183,16 +183,37 @@ def gen_grad_kats(ns):
     print("grad_kats:", {k: v.tolist() for k, v in out.items()})
 
 
+def gen_bundles(ns):
+    """Bundle.sample of the reference, together with the torch.rand values it consumed: Uniform.sample((N,))
+    on [1]-shaped bounds draws torch.rand((N, 1)) once per distribution, in the order the code samples."""
+    n = 4096
+    for name, (mk, kind, par_of, draws) in scenes.bundle_cases(ns).items():
+        b = mk()
+        torch.manual_seed(0)
+        rays = b.sample(n)
+        torch.manual_seed(0)
+        us = [torch.rand((n, 1)).reshape(-1) for _ in range(draws)] + [torch.zeros(n)] * (2 - draws)
+        out = rays_arrays(rays, "")
+        out.update(kind=np.int32(kind), par=np.asarray(par_of(b), dtype=np.float64), ua=npy(us[0]), ub=npy(us[1]),
+                   R=npy(b.transform.rot), t=npy(b.transform.trans), wavelength=npy(rays.wavelength),
+                   ray_id=np.int32(b.ray_id))
+        np.savez_compressed(os.path.join(OUT, f"bundle_{name}.npz"), **out)
+        print("bundle", name, tuple(rays.pos.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_loader.load()
     ns = scenes.namespace_from_package(ref)
+    if sys.argv[1:] == ["bundles"]:
+        return gen_bundles(ns)
     gen_primitives(ns)
     gen_sequential(ns)
     gen_naive(ns)
     gen_spot(ns, torch.float32, "f32")
     gen_spot(ns, torch.float64, "f64")
     gen_grad_kats(ns)
+    gen_bundles(ns)
 
 
 if __name__ == "__main__":

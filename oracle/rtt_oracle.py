@@ -411,3 +411,71 @@ def spot_size_loss(x, y, w, target_xy=None):
     else:
         cx, cy = target_xy
     return torch.sqrt(((x - cx) ** 2 + (y - cy) ** 2) * (w / ws)).sum()
+
+
+# ------------------------------------------------------------------------------------------------
+# Ray sources (rays/bundle.py).  The reference draws uniforms with torch.distributions.Uniform; its
+# formulas are restated here as functions of the unit uniforms so that they can be pinned against the
+# reference (fed with the very torch.rand values it consumed) and then drive the check of the device
+# sampler (fed with the Philox values the kernel uses).
+# ------------------------------------------------------------------------------------------------
+SRC_PENCIL, SRC_DISK, SRC_LINE, SRC_FAN, SRC_POINT = range(5)
+
+
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123): counter [M] uint64 placed in words 0-1, words 2-3
+    zero; key uint64.  Returns [M, 4] uint32."""
+    counter = np.asarray(counter, dtype=np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    c = [counter & m32, counter >> np.uint64(32), np.zeros_like(counter), np.zeros_like(counter)]
+    k0, k1 = np.uint64(int(key) & 0xFFFFFFFF), np.uint64((int(key) >> 32) & 0xFFFFFFFF)
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def philox_uniforms(seed, offset, n):
+    """The two unit uniforms of rays offset .. offset+n-1: the pair of rays (2j, 2j+1) shares block j,
+    ray 2j takes words (0, 1), ray 2j+1 words (2, 3); u = (x >> 8) * 2^-24."""
+    g = np.arange(offset, offset + n, dtype=np.uint64)
+    blocks = philox4x32_10(g >> np.uint64(1), seed)
+    half = (g & np.uint64(1)).astype(np.int64)
+    rows = np.arange(n)
+    to_u = lambda x: ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    return to_u(blocks[rows, 2 * half]), to_u(blocks[rows, 2 * half + 1])
+
+
+def sample_bundle(kind, par, R, t, ua, ub, dtype=torch.float32):
+    """Bundle.sample (rays/bundle.py:30-37) as a function of the unit uniforms ua (first draw) and ub
+    (second draw): local sample (:40-171), RayTransformBundle.transform_ (geom/transform.py:259-262),
+    F.normalize of Rays.__post_init__ (rays/ray.py:22-25).  Returns (pos [N,3], dir [N,3])."""
+    ua, ub = _as(ua, dtype).reshape(-1), _as(ub, dtype).reshape(-1)
+    par = [torch.tensor(float(v), dtype=dtype) for v in list(par) + [0.0] * (4 - len(par))]
+    R = _as(R, dtype).reshape(3, 3)
+    t = _as(t, dtype).reshape(3)
+    n = ua.shape[0]
+    zero, one = torch.zeros(n, dtype=dtype), torch.ones(n, dtype=dtype)
+    between = lambda lo, hi, u: lo + u * (hi - lo)   # torch.distributions.Uniform.rsample
+    p = torch.stack([zero, zero, zero], dim=1)
+    d = torch.stack([zero, zero, one], dim=1)
+    if kind == SRC_DISK:        # rays/bundle.py:47-56 (theta first, then r)
+        theta = between(par[2], par[3], ua)
+        r = torch.sqrt(between(par[0], par[1], ub))
+        p = torch.stack([r * torch.cos(theta), r * torch.sin(theta), zero], dim=1)
+    elif kind == SRC_LINE:      # rays/bundle.py:111-118
+        p = torch.stack([between(par[0], par[1], ua), zero, zero], dim=1)
+    elif kind == SRC_FAN:       # rays/bundle.py:136-140
+        theta = between(par[0], par[1], ua)
+        d = torch.stack([zero, torch.sin(theta), torch.cos(theta)], dim=1)
+    elif kind == SRC_POINT:     # rays/bundle.py:65-75, :162-171 (phi first, then theta)
+        phi = torch.acos(-2 * between(par[0], par[1], ua) + 1)
+        theta = between(par[2], par[3], ub)
+        dr = torch.sin(phi)
+        d = torch.stack([torch.cos(theta) * dr, torch.sin(theta) * dr, torch.cos(phi)], dim=1)
+    pg = _rowmat_T(p, R) + t[None, :]
+    dg = _rowmat_T(d, R)
+    return pg, _normalize(dg)

@@ -37,8 +37,16 @@ _SIGNATURES = {
                                 _i64, _vp],
     "rtt_apply_physics_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "rtt_spot_moments_f32": [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _dbl, _dbl, _vp, _vp],
+    "rtt_sample_bundle_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
 }
 EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune")
+
+
+class RttSource(ctypes.Structure):
+    """Mirror of `RttSource` in include/rtt_hip.h (passed by pointer, read on the host)."""
+    _fields_ = [("kind", ctypes.c_int32), ("ray_id", ctypes.c_int32), ("par", ctypes.c_float * 4),
+                ("R", ctypes.c_float * 9), ("t", ctypes.c_float * 3), ("seed", ctypes.c_uint64),
+                ("offset", ctypes.c_uint64)]
 
 
 class NativeLibraryError(RuntimeError):

@@ -1289,6 +1289,102 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bundle.sample on the device (rays/bundle.py:30-171).  One lane generates the pair of rays with global
+// indices (2j, 2j+1) from one Philox4x32-10 block, applies the bundle transform and the normalisation
+// of Rays.initialize, and writes the structure-of-arrays planes: a write-only kernel.
+// ------------------------------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t x[4];
+};
+
+DI Philox4 philox4x32_10(uint64_t counter, uint64_t key) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return {{c0, c1, c2, c3}};
+}
+
+DI float unit_uniform(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }  // [0, 1), 24 bits
+// torch.distributions.Uniform.rsample: low + rand * (high - low)
+DI float uniform_between(float lo, float hi, float u) { return lo + u * (hi - lo); }
+
+DI void sample_local(const RttSource& src, float ua, float ub, V3<float>& p, V3<float>& d) {
+  p = {0.0f, 0.0f, 0.0f};
+  d = {0.0f, 0.0f, 1.0f};
+  switch (src.kind) {
+    case RTT_SRC_DISK: {  // rays/bundle.py:47-56: theta is drawn before r
+      const float theta = uniform_between(src.par[2], src.par[3], ua);
+      const float r = sqrtf(uniform_between(src.par[0], src.par[1], ub));
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      p = {r * cs, r * sn, 0.0f};
+      break;
+    }
+    case RTT_SRC_LINE:  // rays/bundle.py:111-118
+      p.x = uniform_between(src.par[0], src.par[1], ua);
+      break;
+    case RTT_SRC_FAN: {  // rays/bundle.py:136-140
+      const float theta = uniform_between(src.par[0], src.par[1], ua);
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      d = {0.0f, sn, cs};
+      break;
+    }
+    case RTT_SRC_POINT: {  // rays/bundle.py:65-75, :162-171: phi is drawn before theta
+      const float phi = acosf(-2.0f * uniform_between(src.par[0], src.par[1], ua) + 1.0f);
+      const float theta = uniform_between(src.par[2], src.par[3], ub);
+      float sp, cp, st, ct;
+      sincosf(phi, &sp, &cp);
+      sincosf(theta, &st, &ct);
+      d = {ct * sp, st * sp, cp};
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, float* __restrict__ pos, float* __restrict__ dir,
+                                                          int64_t ld, float* __restrict__ inten, int8_t* __restrict__ id,
+                                                          float* __restrict__ wavelength, int64_t n) {
+  const uint64_t first_pair = src.offset >> 1;
+  const uint64_t pair = first_pair + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const Philox4 rnd = philox4x32_10(pair, src.seed);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint64_t g = 2 * pair + h;  // global ray index
+    if (g < src.offset || g >= src.offset + (uint64_t)n) continue;
+    const int64_t i = (int64_t)(g - src.offset);
+    V3<float> p, d;
+    sample_local(src, unit_uniform(rnd.x[2 * h]), unit_uniform(rnd.x[2 * h + 1]), p, d);
+    // RayTransformBundle.transform_: pos @ R^T + t, dir @ R^T (geom/transform.py:259-262)
+    const float* R = src.R;
+    const V3<float> pg = {p.x * R[0] + p.y * R[1] + p.z * R[2] + src.t[0], p.x * R[3] + p.y * R[4] + p.z * R[5] + src.t[1],
+                          p.x * R[6] + p.y * R[7] + p.z * R[8] + src.t[2]};
+    V3<float> dg = {d.x * R[0] + d.y * R[1] + d.z * R[2], d.x * R[3] + d.y * R[4] + d.z * R[5],
+                    d.x * R[6] + d.y * R[7] + d.z * R[8]};
+    // Rays.__post_init__: F.normalize(dir) = dir / max(|dir|, 1e-12) (rays/ray.py:22-25)
+    const float len = fmaxf(sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z), 1e-12f);
+    dg = {dg.x / len, dg.y / len, dg.z / len};
+    pos[i] = pg.x; pos[ld + i] = pg.y; pos[2 * ld + i] = pg.z;
+    dir[i] = dg.x; dir[ld + i] = dg.y; dir[2 * ld + i] = dg.z;
+    if (inten) inten[i] = 1.0f;
+    if (id) id[i] = (int8_t)src.ray_id;
+    if (wavelength) wavelength[i] = 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 // tuning knobs (rtt_tune): rays carried per lane in the sequential trace, and the grid cap
@@ -1566,6 +1662,20 @@ int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const u
   if (n == 0) return RTT_OK;
   hipLaunchKernelGGL(k_spot_moments, dim3(grid_for_reduction(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w, mask, n,
                      pass, cx, cy, wsum, out);
+  return launch_status();
+}
+
+int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t ld, float* inten, int8_t* id,
+                          float* wavelength, int64_t n, void* stream) {
+  if (!src || !pos || !dir) return RTT_E_NULL;
+  if (n < 0 || ld < n) return RTT_E_SIZE;
+  if (src->kind < RTT_SRC_PENCIL || src->kind > RTT_SRC_POINT) return RTT_E_KIND;
+  if (misaligned(pos) || misaligned(dir) || misaligned(inten) || misaligned(wavelength)) return RTT_E_ALIGN;
+  if (n == 0) return RTT_OK;
+  const uint64_t first_pair = src->offset >> 1, last_pair = (src->offset + (uint64_t)n - 1) >> 1;
+  const uint64_t pairs = last_pair - first_pair + 1;
+  hipLaunchKernelGGL(k_sample_bundle, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                     *src, pos, dir, ld, inten, id, wavelength, n);
   return launch_status();
 }
 

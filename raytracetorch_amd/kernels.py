@@ -173,3 +173,34 @@ def spot_moments(x, y, w, mask, pass_id: int, cx: float, cy: float, wsum: float,
                                                 N.stream_handle(x.device))
         N.check(code, "rtt_spot_moments_f32")
     return out
+
+
+SRC_PENCIL, SRC_DISK, SRC_LINE, SRC_FAN, SRC_POINT = range(5)
+
+
+def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: int, n: int, device) -> Rays:
+    """Bundle.sample(N) on the device: local sample, bundle pose, normalisation, ids (one write-only kernel).
+    `rot` is the 3x3 local->global rotation, `trans` the translation; rays get the Philox values of the
+    global indices offset .. offset+n-1."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("sample_bundle generates rays on a HIP device only")
+    import ctypes
+    src = N.RttSource()
+    src.kind, src.ray_id = int(kind), int(ray_id)
+    par = [float(v) for v in par] + [0.0] * (4 - len(par))
+    src.par = (ctypes.c_float * 4)(*par)
+    src.R = (ctypes.c_float * 9)(*[float(v) for v in torch.as_tensor(rot, dtype=torch.float32).reshape(-1).tolist()])
+    src.t = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(trans, dtype=torch.float32).reshape(-1).tolist()])
+    src.seed, src.offset = int(seed) & (2 ** 64 - 1), int(offset)
+    pos = torch.empty((3, n), device=device, dtype=torch.float32)
+    dir_ = torch.empty((3, n), device=device, dtype=torch.float32)
+    inten = torch.empty((n,), device=device, dtype=torch.float32)
+    ids = torch.empty((n,), device=device, dtype=torch.int8)
+    wl = torch.empty((n,), device=device, dtype=torch.float32)
+    if n:
+        with torch.cuda.device(device):
+            code = N.lib().rtt_sample_bundle_f32(ctypes.addressof(src), N.ptr(pos), N.ptr(dir_), n, N.ptr(inten),
+                                                 N.ptr(ids), N.ptr(wl), n, N.stream_handle(device))
+        N.check(code, "rtt_sample_bundle_f32")
+    return Rays.from_planes(pos, dir_, inten, ids, wl)

@@ -204,3 +204,23 @@ def random_system(ns, rng):
         z += float(rng.uniform(6.0, 10.0))
     els.append(ns.Sensor(ns.Disk(15.0, transform=ns.RayTransform(translation=[0.0, 0.0, z]))))
     return els
+
+
+# ---------------------------------------------------------------------------------------------
+# ray-source cases (rays/bundle.py)
+# ---------------------------------------------------------------------------------------------
+def bundle_cases(ns):
+    """name -> (constructor, device-sampler kind, parameters, number of uniform draws per ray)."""
+    import math
+    pose = lambda: ns.RayTransformBundle(rotation=[0.1, -0.2, 0.05], translation=[1.0, -2.0, -30.0])
+    return {
+        "pencil": (lambda: ns.Bundle(ray_id=3, transform=pose()), 0, lambda b: (), 0),
+        "disk": (lambda: ns.CollimatedDisk(radius=4.0, ray_id=1, transform=pose()), 1,
+                 lambda b: (0.0, float(b.radius2), 0.0, 2 * math.pi), 2),
+        "disk_unposed": (lambda: ns.CollimatedDisk(radius=2.5, ray_id=0), 1,
+                         lambda b: (0.0, float(b.radius2), 0.0, 2 * math.pi), 2),
+        "line": (lambda: ns.CollimatedLine(length=3.0, ray_id=2, transform=pose()), 2, lambda b: (-3.0, 3.0), 1),
+        "fan": (lambda: ns.Fan(angle=0.6, ray_id=4, transform=pose()), 3, lambda b: (-0.3, 0.3), 1),
+        "point": (lambda: ns.PointSource(NA=0.25, ray_id=5, transform=pose()), 4,
+                  lambda b: (0.0, float(b.F_phi_max), 0.0, 2 * math.pi), 2),
+    }
