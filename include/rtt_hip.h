@@ -70,7 +70,13 @@ enum {
   RTT_PHYS_REFLECT = 2,  /* std.py:91-108  */
   RTT_PHYS_SNELL = 3,    /* std.py:111-145; phys[0]=ior_in, phys[1]=ior_out,
                             phys[2]=ior_out/ior_in, phys[3]=ior_in/ior_out */
-  RTT_PHYS_APERTURE = 4  /* filter.py:10-33: dir*=m, imult=m, m = surface bound without invert */
+  RTT_PHYS_APERTURE = 4, /* filter.py:10-33: dir*=m, imult=m, m = surface bound without invert */
+  RTT_PHYS_LINEAR = 5,   /* std.py:35-88: paraxial element; phys = Cx, Cy, Dx, Dy; the functor's rotation is
+                            phys_R, or Rj when RTT_F_PHYS_ROT_SURF is set (elements/ideal.py:47-55) */
+  RTT_PHYS_FRESNEL = 6   /* std.py:148-219: Snell refraction or mirror reflection, chosen per ray by
+                            u < R(Fresnel); phys as RTT_PHYS_SNELL.  u is word 2*(i&1) of the Philox4x32-10
+                            block with counter (i >> 1) and key seed + surface position in the program,
+                            u = (x >> 8) * 2^-24, i = index of the ray in the call */
 };
 
 /* flags */
@@ -79,6 +85,7 @@ enum {
 #define RTT_F_SURF_ROT_ID 4  /* Rj is exactly the identity */
 #define RTT_F_INVERT 8       /* SurfaceBounded.invert (geom/bounded.py:29-30) */
 #define RTT_F_SENSOR 16      /* Sensor element: record hit_local, intensity (elements/sensor.py:35-37) */
+#define RTT_F_PHYS_ROT_SURF 32 /* RTT_PHYS_LINEAR rotates with the surface transform Rj (LinearElement) */
 
 /* One record per (element, surface), 256 bytes, packed on the host from the live parameters. */
 typedef struct RttSurface {
@@ -90,7 +97,9 @@ typedef struct RttSurface {
   float bnd[4];
   float shp[8];
   float phys[4];
-  float pad[12];
+  float phys_R[9];    /* rotation of a Linear functor that carries its own transform (phys/std.py:51-54) */
+  uint32_t seed[2];   /* Philox key (lo, hi) of RTT_PHYS_FRESNEL, drawn by the host for every trace */
+  float pad[1];
 } RttSurface;
 
 /* ---- fused sequential trace: SequentialScene.simulate (scene/sequential.py:12-36) --------------

@@ -39,8 +39,10 @@ def clone_rays(ns, rays):
                    id=rays.id.clone(), wavelength=rays.wavelength.clone(), batch_size=rays.batch_size)
 
 
-def gen_sequential(ns):
+def gen_sequential(ns, only=None):
     for name, (mk_elements, mk_rays, n) in scenes.sequential_cases(ns).items():
+        if only and name not in only:
+            continue
         torch.manual_seed(0)
         elements = mk_elements()
         rays0 = mk_rays(n)
@@ -201,12 +203,34 @@ def gen_bundles(ns):
         print("bundle", name, tuple(rays.pos.shape))
 
 
+def gen_physics(ns):
+    """Functors called directly.  RefractFresnel consumes torch.rand_like(R) ([N,1]) once per call; the same
+    values are recorded by re-seeding."""
+    n = 4096
+    for name, (mk, inputs) in scenes.physics_cases(ns).items():
+        torch.manual_seed(1)
+        hl, d, nrm = inputs(n)
+        f = mk()
+        torch.manual_seed(0)
+        with torch.no_grad():
+            nd, im = f(hl, d, nrm)
+        torch.manual_seed(0)
+        u = torch.rand((n, 1))
+        np.savez_compressed(os.path.join(OUT, f"phys_{name}.npz"), hit_local=npy(hl), dir=npy(d), normal=npy(nrm),
+                            new_dir=npy(nd), imult=npy(im), u=npy(u))
+        print("phys", name)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_loader.load()
     ns = scenes.namespace_from_package(ref)
     if sys.argv[1:] == ["bundles"]:
         return gen_bundles(ns)
+    if sys.argv[1:] == ["physics"]:
+        return gen_physics(ns)
+    if sys.argv[1:2] == ["seq"]:
+        return gen_sequential(ns, only=sys.argv[2:])
     gen_primitives(ns)
     gen_sequential(ns)
     gen_naive(ns)
@@ -214,6 +238,7 @@ def main():
     gen_spot(ns, torch.float64, "f64")
     gen_grad_kats(ns)
     gen_bundles(ns)
+    gen_physics(ns)
 
 
 if __name__ == "__main__":

@@ -27,15 +27,15 @@ SURFACE_DTYPE = np.dtype([
     ("flags", "<i4"), ("element_id", "<i4"), ("surface_id", "<i4"), ("sensor_slot", "<i4"),
     ("Rs", "<f4", (9,)), ("ts", "<f4", (3,)), ("Rj", "<f4", (9,)), ("tj", "<f4", (3,)),
     ("geom", "<f4", (4,)), ("bnd", "<f4", (4,)), ("shp", "<f4", (8,)), ("phys", "<f4", (4,)),
-    ("pad", "<f4", (12,)),
+    ("phys_R", "<f4", (9,)), ("seed", "<u4", (2,)), ("pad", "<f4", (1,)),
 ])
 assert SURFACE_DTYPE.itemsize == 256
 
 PLANE, QUADRIC, QUADRIC_ZY, CYLINDER, SPHERE, CONE = range(6)
 B_NONE, B_DISK, B_RECT, B_ELLIPSE, B_HALF, B_HALF_DISK, B_SINGLE_CONE, B_ALWAYS = range(8)
 S_NONE, S_SPHERIC_FACE, S_SPHERIC_EDGE, S_CYL_FACE, S_CYL_EDGE = range(5)
-P_TRANSMIT, P_BLOCK, P_REFLECT, P_SNELL, P_APERTURE = range(5)
-F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR = 1, 2, 4, 8, 16
+P_TRANSMIT, P_BLOCK, P_REFLECT, P_SNELL, P_APERTURE, P_LINEAR, P_FRESNEL = range(7)
+F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR, F_PHYS_ROT_SURF = 1, 2, 4, 8, 16, 32
 
 
 class _Rec:
@@ -51,6 +51,8 @@ class _Rec:
         self.Rj = t(rec["Rj"]).reshape(3, 3); self.tj = t(rec["tj"])
         self.geom = t(rec["geom"]); self.bnd = t(rec["bnd"]); self.shp = t(rec["shp"])
         self.phys = t(rec["phys"])
+        self.phys_R = t(rec["phys_R"]).reshape(3, 3)
+        self.seed = int(rec["seed"][0]) | (int(rec["seed"][1]) << 32)
         self.dtype = dtype
 
 
@@ -293,8 +295,20 @@ def surface_forward(S, p, d):
     return t, hit_g, n, hl
 
 
-def apply_physics(S, hl, d, n):
-    """SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult)."""
+def fresnel_uniforms(S, n, u=None):
+    """The uniforms of RefractFresnel's choice (phys/std.py:200): given ones (pinning against the
+    reference's torch.rand values), or the Philox words the kernels use for rays 0..n-1 of a call:
+    word 2*(i&1) of block (i >> 1) under key seed + (element_id << 8) + surface_id."""
+    if u is not None:
+        return _as(u, S.dtype).reshape(-1, 1)
+    key = (S.seed + (S.element_id << 8) + S.surface_id) & (2 ** 64 - 1)
+    ua, _ = philox_uniforms(key, 0, n)
+    return torch.from_numpy(ua).to(S.dtype).reshape(-1, 1)
+
+
+def apply_physics(S, hl, d, n, u=None):
+    """SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult).
+    `u` optionally supplies the uniforms of the stochastic functor."""
     k = S.phys_kind
     ones = torch.ones_like(d[:, 0])
     if k == P_TRANSMIT:  # std.py:227-235
@@ -319,6 +333,31 @@ def apply_physics(S, hl, d, n):
     if k == P_APERTURE:  # filter.py:24-33
         m = surface_in_bounds(S, hl).to(d.dtype)
         return d * m[:, None], m
+    if k == P_FRESNEL:  # std.py:177-219
+        dot = (d[:, 0] * n[:, 0] + d[:, 1] * n[:, 1] + d[:, 2] * n[:, 2])[:, None]
+        ent = dot < 0
+        ne = torch.where(ent, n, -n)
+        ci = torch.abs(dot)
+        n1 = torch.where(ent, S.phys[0], S.phys[1])
+        n2 = torch.where(ent, S.phys[1], S.phys[0])
+        mu = n2 / n1
+        sin2 = (mu ** 2) * (1.0 - ci ** 2)
+        tir = sin2 > 1.0
+        ct = torch.sqrt(torch.relu(1.0 - sin2))
+        rs = ((n1 * ci - n2 * ct) / (n1 * ci + n2 * ct + 1e-8)) ** 2
+        rp = ((n1 * ct - n2 * ci) / (n1 * ct + n2 * ci + 1e-8)) ** 2
+        R = torch.where(tir, torch.ones_like(rs), 0.5 * (rs + rp))
+        reflect = fresnel_uniforms(S, d.shape[0], u) < R
+        refl = d - 2 * dot * n
+        refr = mu * d + (mu * ci - ct) * ne
+        return torch.where(reflect, refl, refr), ones
+    if k == P_LINEAR:  # std.py:72-88
+        Rp = S.Rj if (S.flags & F_PHYS_ROT_SURF) else S.phys_R
+        dl = _rowmat(d, Rp)
+        dl = dl / dl[:, 2][:, None]
+        v = torch.stack([S.phys[0] * hl[:, 0] + S.phys[2] * dl[:, 0], S.phys[1] * hl[:, 1] + S.phys[3] * dl[:, 1],
+                         torch.ones_like(hl[:, 0])], dim=1)
+        return _rowmat_T(_normalize(v), Rp), ones
     raise ValueError(k)
 
 

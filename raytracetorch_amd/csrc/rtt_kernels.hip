@@ -116,6 +116,20 @@ DI float sqrt_disc(float x) {
 DI f2 sqrt_disc(f2 x) { return f2{sqrt_disc(x.x), sqrt_disc(x.y)}; }
 DI float quot(float a, float b) { return kStrict ? a / b : a * rcp_(b); }
 DI f2 quot(f2 a, f2 b) { return kStrict ? a / b : a * rcp_(b); }
+// a / b from the hardware reciprocal plus one correction step on the exact residual fma(-b, q, a): within
+// half an ulp (+ 2^-24 relative) of the true quotient.  Used where the quotient is a path length.
+DI float quot_refined(float a, float b) {
+  if (kStrict) return a / b;
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+DI f2 quot_refined(f2 a, f2 b) {
+  if (kStrict) return a / b;
+  const f2 r = rcp_(b);
+  const f2 q = a * r;
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(-b, q, a), r, q);
+}
 template <class T> DI T splat(float v) { return T(v); }
 DI float comp(float a, int) { return a; }
 DI float comp(f2 a, int k) { return k == 0 ? a.x : a.y; }
@@ -171,9 +185,36 @@ template <int K> DI Dual<K> sqrt_disc(Dual<K> a) { const float s = sqrt_disc(a.v
 template <int K> DI Dual<K> sqrt_ieee(Dual<K> a) { const float s = sqrtf(a.v); return chain(a, s, 0.5f / s); }
 template <int K> DI Dual<K> rsq_(Dual<K> a) { const float r = rsq_(a.v); return chain(a, r, -0.5f * r * r * r); }
 template <int K> DI Dual<K> quot(Dual<K> a, Dual<K> b) { return a * rcp_(b); }
+template <int K> DI Dual<K> quot_refined(Dual<K> a, Dual<K> b) {
+  Dual<K> q = a * rcp_(b);
+  q.v = quot_refined(a.v, b.v);
+  return q;
+}
 template <int K> DI Dual<K> div_ieee(Dual<K> a, Dual<K> b) { return a * rcp_(b); }
 template <int K> DI float comp(Dual<K> a, int) { return a.v; }
 #undef RTT_DUAL_LOOP
+
+// Philox4x32-10 (Salmon et al. 2011): counter words (c lo, c hi, 0, 0), 64-bit key.
+struct Philox4 {
+  uint32_t x[4];
+};
+
+DI Philox4 philox4x32_10(uint64_t counter, uint64_t key) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return {{c0, c1, c2, c3}};
+}
 
 template <class T>
 struct V3 {
@@ -258,6 +299,7 @@ __device__ __forceinline__ int op_of(const Ops& ops, int s) { return (ops.w[s >>
 struct RecF {
   const RttSurface& r;
   DI float Rs(int i) const { return r.Rs[i]; }
+  DI float Rp(int i) const { return (r.flags & RTT_F_PHYS_ROT_SURF) ? r.Rj[i] : r.phys_R[i]; }
   DI float ts(int i) const { return r.ts[i]; }
   DI float Rj(int i) const { return r.Rj[i]; }
   DI float tj(int i) const { return r.tj[i]; }
@@ -272,6 +314,7 @@ struct RecF {
 struct RecL {
   const RttSurface& r;  // LDS-resident record
   DI float Rs(int i) const { return r.Rs[i]; }
+  DI float Rp(int i) const { return (r.flags & RTT_F_PHYS_ROT_SURF) ? r.Rj[i] : r.phys_R[i]; }
   DI float ts(int i) const { return r.ts[i]; }
   DI float Rj(int i) const { return r.Rj[i]; }
   DI float tj(int i) const { return r.tj[i]; }
@@ -297,6 +340,8 @@ struct RecD {
     return d;
   }
   DI Dual<K> Rs(int i) const { return mk(r.Rs[i], i); }
+  // a Linear functor's own rotation is not a differentiable slot; the surface rotation is
+  DI Dual<K> Rp(int i) const { return (r.flags & RTT_F_PHYS_ROT_SURF) ? mk(r.Rj[i], 12 + i) : Dual<K>(r.phys_R[i]); }
   DI Dual<K> ts(int i) const { return mk(r.ts[i], 9 + i); }
   DI Dual<K> Rj(int i) const { return mk(r.Rj[i], 12 + i); }
   DI Dual<K> tj(int i) const { return mk(r.tj[i], 21 + i); }
@@ -307,10 +352,10 @@ struct RecD {
 };
 
 // v @ R, R row-major (geom/transform.py:92-93); W = 0 takes the element rotation Rs, W = 1 the surface
-// rotation Rj.  `ident` skips the products: with R exactly the identity x*1 + y*0 + z*0 == x bit for bit.
+// rotation Rj, W = 2 the rotation of a Linear functor.  `ident` skips the products: with R exactly the identity x*1 + y*0 + z*0 == x bit for bit.
 template <int W, class RV>
 DI auto rot(const RV& S, int i) -> decltype(S.Rs(0)) {
-  return W == 0 ? S.Rs(i) : S.Rj(i);
+  return W == 0 ? S.Rs(i) : (W == 1 ? S.Rj(i) : S.Rp(i));
 }
 
 template <int W, class T, class RV>
@@ -414,7 +459,7 @@ DI int solve_roots(const RV& S, V3<T> o, V3<T> d, T& t1, T& t2, M& ok) {
   switch (C::sk(S.r)) {
     case RTT_SURF_PLANE: {  // geom/primitives.py:124-136
       const T safe = sel(lt(abs_(d.z), splat<T>(kEps)), splat<T>(1e-8f), d.z);
-      t1 = quot(-o.z, safe);
+      t1 = quot_refined(-o.z, safe);
       t2 = t1;
       ok = mask_all<M>(true);
       return 1;
@@ -669,9 +714,27 @@ DI Forward<T> surface_forward(const RV& S, V3<T> p, V3<T> d, const Frames<T>& f,
   return o;
 }
 
-// SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult)
+// The uniform of RefractFresnel's Monte-Carlo choice (phys/std.py:200) for the ray with index r of the call:
+// word 2*(r&1) of the Philox block (r >> 1) under `key`.
+DI float unit_uniform(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }  // [0, 1), 24 bits
+DI float fresnel_uniform(uint64_t key, uint64_t r, float*) {
+  return unit_uniform(philox4x32_10(r >> 1, key).x[2 * (r & 1)]);
+}
+DI f2 fresnel_uniform(uint64_t key, uint64_t r, f2*) {
+  if ((r & 1) == 0) {  // the usual case: one block serves the lane's two rays
+    const Philox4 b = philox4x32_10(r >> 1, key);
+    return f2{unit_uniform(b.x[0]), unit_uniform(b.x[2])};
+  }
+  return f2{fresnel_uniform(key, r, (float*)nullptr), fresnel_uniform(key, r + 1, (float*)nullptr)};
+}
+template <int K> DI Dual<K> fresnel_uniform(uint64_t key, uint64_t r, Dual<K>*) {
+  return Dual<K>(fresnel_uniform(key, r, (float*)nullptr));
+}
+
+// SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult); `ridx` is the index in
+// the call of the lane's (first) ray, used by the stochastic functor only.
 template <class C, class RV, class T>
-DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im) {
+DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im, uint64_t ridx) {
   const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
   switch (C::pk(S.r)) {
     case RTT_PHYS_BLOCK:  // phys/std.py:243-254
@@ -701,6 +764,42 @@ DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im)
         const T two_dot = 2.0f * dot;
         nd = sel3(tir, d - scale(two_dot, n), refr);
       }
+      im = one;
+      return;
+    }
+    case RTT_PHYS_FRESNEL: {  // phys/std.py:177-219
+      const T dot = dot3(d, n);
+      const auto ent = lt(dot, zero);
+      const T ci = abs_(dot);
+      const T n1 = sel(ent, T(S.phys(0)), T(S.phys(1)));
+      const T n2 = sel(ent, T(S.phys(1)), T(S.phys(0)));
+      const T mu = sel(ent, T(S.phys(2)), T(S.phys(3)));  // n2 / n1
+      const T sin2 = mu * mu * (1.0f - ci * ci);
+      const auto tir = gt(sin2, splat<T>(1.0f));
+      const T ct = sqrt_(max_(1.0f - sin2, zero));
+      const T n1ci = n1 * ci, n2ct = n2 * ct, n1ct = n1 * ct, n2ci = n2 * ci;
+      const T rs = quot(n1ci - n2ct, n1ci + n2ct + 1e-8f);
+      const T rp = quot(n1ct - n2ci, n1ct + n2ci + 1e-8f);
+      const T R = sel(tir, splat<T>(1.0f), 0.5f * (rs * rs + rp * rp));
+      const uint64_t key = ((uint64_t)S.r.seed[1] << 32 | S.r.seed[0]) + ((uint64_t)S.r.element_id << 8) + (uint64_t)S.r.surface_id;
+      const T u = fresnel_uniform(key, ridx, (T*)nullptr);
+      const auto reflect = lt(u, R);
+      const T g = sel(ent, mu * ci - ct, ct - mu * ci);  // (mu ci - ct) * (entering ? n : -n)
+      const V3<T> refr = scale(mu, d) + scale(g, n);
+      const T two_dot = 2.0f * dot;
+      nd = sel3(reflect, d - scale(two_dot, n), refr);
+      im = one;
+      return;
+    }
+    case RTT_PHYS_LINEAR: {  // phys/std.py:72-88
+      V3<T> dl = rowmat<2>(d, S, false);
+      // correctly rounded quotients and root: a paraxial element is usually followed by a long free path to
+      // its focus, which multiplies every ulp of the outgoing slope
+      const T nx = T(S.phys(0)) * hl.x + T(S.phys(2)) * div_ieee(dl.x, dl.z);
+      const T ny = T(S.phys(1)) * hl.y + T(S.phys(3)) * div_ieee(dl.y, dl.z);
+      // F.normalize: v / max(|v|, 1e-12); |v| >= 1 here
+      const T len = sqrt_ieee(nx * nx + ny * ny + 1.0f);
+      nd = rowmat_t<2>(V3<T>{div_ieee(nx, len), div_ieee(ny, len), div_ieee(splat<T>(1.0f), len)}, S, false);
       im = one;
       return;
     }
@@ -734,6 +833,7 @@ struct SensorIO {
   float* w;
   uint8_t* mask;
   int64_t ld;
+  int64_t index0;  // index in the call of the ray that element 0 of these (possibly tile-shifted) planes holds
 };
 
 template <class T>
@@ -817,7 +917,7 @@ DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, con
   Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
   V3<T> nd;
   T im;
-  apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im);
+  apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)(se.index0 + (int64_t)i));
   if (sensor) record_sensor(se, S.r.sensor_slot, i, hit, fw.hit_l, r.I, nv);
   if (__all(all_(hit))) {  // every ray of the wavefront hits: plain moves, no selects
     r.p = fw.hit_g;
@@ -869,7 +969,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
     const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in,
                        io.pos_out + base, io.dir_out + base, io.inten_out + base, io.ld_out, io.n - base};
     const SensorIO tse = {se.hit ? se.hit + base : nullptr, se.w ? se.w + base : nullptr,
-                          se.mask ? se.mask + base : nullptr, se.ld};
+                          se.mask ? se.mask + base : nullptr, se.ld, base};
     Ray<T> r[G];
     uint32_t idx[G];
     int nv[G];
@@ -965,7 +1065,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
       Forward<T> fw = surface_forward<CGeneric>(S, r.p, r.d, f, t_raw);
       V3<T> nd;
       T im;
-      apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im);
+      apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)i);
       if (S.r.flags & RTT_F_SENSOR) {
         if (SPOT) {
           const float w = r.I.v;
@@ -1209,7 +1309,7 @@ __global__ void __launch_bounds__(kBlock) k_surface_forward(const float* __restr
     if (o.new_dir || o.imult) {
       V3<float> nd;
       float im;
-      apply_physics<CGeneric>(S, fw.hit_l, d, fw.n_g, nd, im);
+      apply_physics<CGeneric>(S, fw.hit_l, d, fw.n_g, nd, im, (uint64_t)i);
       store3(o.new_dir, o.ld, i, nd);
       if (o.imult) o.imult[i] = im;
     }
@@ -1228,7 +1328,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_physics(const float* __restric
     V3<float> nn = {nrm[i], nrm[ld + i], nrm[2 * ld + i]};
     V3<float> nd;
     float im;
-    apply_physics<CGeneric>(S, h, d, nn, nd, im);
+    apply_physics<CGeneric>(S, h, d, nn, nd, im, (uint64_t)i);
     store3(new_dir, ld, i, nd);
     imult[i] = im;
   }
@@ -1293,28 +1393,6 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
 // indices (2j, 2j+1) from one Philox4x32-10 block, applies the bundle transform and the normalisation
 // of Rays.initialize, and writes the structure-of-arrays planes: a write-only kernel.
 // ------------------------------------------------------------------------------------------------
-struct Philox4 {
-  uint32_t x[4];
-};
-
-DI Philox4 philox4x32_10(uint64_t counter, uint64_t key) {
-  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
-  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1;
-    c3 = (uint32_t)p0;
-    c0 = n0;
-    c2 = n2;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return {{c0, c1, c2, c3}};
-}
-
-DI float unit_uniform(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }  // [0, 1), 24 bits
 // torch.distributions.Uniform.rsample: low + rand * (high - low)
 DI float uniform_between(float lo, float hi, float u) { return lo + u * (hi - lo); }
 
@@ -1451,7 +1529,7 @@ int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_s
     if (S.surf_kind < RTT_SURF_PLANE || S.surf_kind > RTT_SURF_CONE) return RTT_E_KIND;
     if (S.bound_kind < RTT_BND_NONE || S.bound_kind > RTT_BND_ALWAYS) return RTT_E_KIND;
     if (S.shape_kind < RTT_SHP_NONE || S.shape_kind > RTT_SHP_CYL_EDGE) return RTT_E_KIND;
-    if (S.phys_kind < RTT_PHYS_TRANSMIT || S.phys_kind > RTT_PHYS_APERTURE) return RTT_E_KIND;
+    if (S.phys_kind < RTT_PHYS_TRANSMIT || S.phys_kind > RTT_PHYS_FRESNEL) return RTT_E_KIND;
     if ((S.shape_kind != RTT_SHP_NONE) != ((S.flags & RTT_F_HAS_SHAPE) != 0)) return RTT_E_KIND;
     if ((S.flags & RTT_F_SENSOR) && any_sensor) {  // slots only matter to entry points that record
       if (S.sensor_slot < 0 || S.sensor_slot >= RTT_MAX_SURFACES) return RTT_E_SIZE;
@@ -1646,7 +1724,7 @@ int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float*
   if (n < 0 || ld < n) return RTT_E_SIZE;
   if (misaligned(hit_local) || misaligned(dir) || misaligned(normal) || misaligned(new_dir) || misaligned(imult))
     return RTT_E_ALIGN;
-  if (prog_host && (prog_host->phys_kind < RTT_PHYS_TRANSMIT || prog_host->phys_kind > RTT_PHYS_APERTURE))
+  if (prog_host && (prog_host->phys_kind < RTT_PHYS_TRANSMIT || prog_host->phys_kind > RTT_PHYS_FRESNEL))
     return RTT_E_KIND;
   if (n == 0) return RTT_OK;
   hipLaunchKernelGGL(k_apply_physics, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, hit_local, dir,

@@ -3,3 +3,5 @@ from .lens import SingletLens, CylSingletLens, DoubletLens, TripletLens
 from .sensor import Sensor
 from .mirror import Mirror, SphericalMirror, CylindricalMirror, ParabolicMirror, ParabolicMirrorXZ
 from .aperture import CircularAperture, RectangularAperture, EllipticAperture
+from .ideal import (LinearElement, IdealThinLens, IdealCylThinLens, IdealMirror, ParaxialLensMat, ParaxialDistMat,
+                    ParaxialRefractMat, ParaxialMirrorMat)

@@ -10,14 +10,14 @@ import torch
 import torch.nn as nn
 
 from ..geom import CylSinglet, Doublet, RayTransform, Singlet, Triplet
-from ..phys import Block, RefractSnell
+from ..phys import Block, RefractFresnel, RefractSnell
 from .parent import Element
 
 
-def _snell(ior_in: nn.Parameter, ior_out: nn.Parameter) -> RefractSnell:
-    """Functor whose index attributes are the given Parameter objects themselves
-    (elements/lens.py:41-49)."""
-    sf = RefractSnell(ior_in=0.0, ior_out=0.0)
+def _snell(ior_in: nn.Parameter, ior_out: nn.Parameter, fresnel: bool = False) -> RefractSnell:
+    """Functor whose index attributes are the given Parameter objects themselves; `fresnel` selects the
+    stochastic RefractFresnel instead of RefractSnell (elements/lens.py:36-49)."""
+    sf = (RefractFresnel if fresnel else RefractSnell)(ior_in=1.0, ior_out=1.0)
     sf.ior_in = ior_in
     sf.ior_out = ior_out
     return sf
@@ -25,11 +25,6 @@ def _snell(ior_in: nn.Parameter, ior_out: nn.Parameter) -> RefractSnell:
 
 def _ior(v, grad):
     return nn.Parameter(torch.as_tensor(v, dtype=torch.float32), requires_grad=grad)
-
-
-def _no_fresnel(fresnel):
-    if fresnel:
-        raise NotImplementedError("RefractFresnel (stochastic reflection) is not part of the HIP path yet")
 
 
 class SingletLens(Element):
@@ -41,14 +36,13 @@ class SingletLens(Element):
                  ior_glass_grad: bool = False, ior_media_grad: bool = False,
                  fresnel: bool = False, inked: bool = False, transform: Optional[RayTransform] = None):
         super().__init__()
-        _no_fresnel(fresnel)
         self.ior_glass = _ior(ior_glass, ior_glass_grad)
         self.ior_media = _ior(ior_media, ior_media_grad)
         self.shape = Singlet(C1=c1, C2=c2, D=d, T=t, C1_grad=c1_grad, C2_grad=c2_grad, D_grad=d_grad,
                              T_grad=t_grad, transform=transform)
-        self.surface_functions.append(_snell(self.ior_glass, self.ior_media))
-        self.surface_functions.append(_snell(self.ior_media, self.ior_glass))
-        self.surface_functions.append(Block() if inked else _snell(self.ior_glass, self.ior_media))
+        self.surface_functions.append(_snell(self.ior_glass, self.ior_media, fresnel))
+        self.surface_functions.append(_snell(self.ior_media, self.ior_glass, fresnel))
+        self.surface_functions.append(Block() if inked else _snell(self.ior_glass, self.ior_media, fresnel))
 
     # paraxial conveniences (elements/lens.py:60-127)
     @property
@@ -120,7 +114,6 @@ class DoubletLens(Element):
                  ior_glass1_grad=False, ior_glass2_grad=False, ior_media_grad=False,
                  fresnel=False, inked=True, transform: Optional[RayTransform] = None):
         super().__init__()
-        _no_fresnel(fresnel)
         self.ior_glass1 = _ior(ior_glass1, ior_glass1_grad)
         self.ior_glass2 = _ior(ior_glass2, ior_glass2_grad)
         self.ior_media = _ior(ior_media, ior_media_grad)
@@ -129,7 +122,7 @@ class DoubletLens(Element):
                              transform=transform)
         chain = [self.ior_media, self.ior_glass1, self.ior_glass2, self.ior_media]
         for a, b in zip(chain[:-1], chain[1:]):
-            self.surface_functions.append(_snell(a, b))
+            self.surface_functions.append(_snell(a, b, fresnel))
         for _ in range(2):
             self.surface_functions.append(Block())
 
@@ -146,7 +139,6 @@ class TripletLens(Element):
                  ior_glass1_grad=False, ior_glass2_grad=False, ior_glass3_grad=False, ior_media_grad=False,
                  fresnel=False, inked=True, transform: Optional[RayTransform] = None):
         super().__init__()
-        _no_fresnel(fresnel)
         self.ior_glass1 = _ior(ior_glass1, ior_glass1_grad)
         self.ior_glass2 = _ior(ior_glass2, ior_glass2_grad)
         self.ior_glass3 = _ior(ior_glass3, ior_glass3_grad)
@@ -157,7 +149,7 @@ class TripletLens(Element):
                              transform=transform)
         chain = [self.ior_media, self.ior_glass1, self.ior_glass2, self.ior_glass3, self.ior_media]
         for a, b in zip(chain[:-1], chain[1:]):
-            self.surface_functions.append(_snell(a, b))
+            self.surface_functions.append(_snell(a, b, fresnel))
         for _ in range(3):
             self.surface_functions.append(Block())
 

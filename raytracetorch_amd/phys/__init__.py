@@ -1,2 +1,2 @@
-from .std import SurfaceFunction, Reflect, RefractSnell, Transmit, Block
+from .std import SurfaceFunction, Reflect, RefractSnell, RefractFresnel, Linear, Transmit, Block
 from .filter import ApertureFilter

@@ -65,3 +65,47 @@ class RefractSnell(SurfaceFunction):
     def _diff_phys(self):
         a, b = self.ior_in, self.ior_out
         return torch.stack([a, b, b / a, a / b])
+
+
+class RefractFresnel(RefractSnell):
+    """Stochastic refraction / reflection (phys/std.py:148-219): a ray is mirror-reflected with the
+    unpolarised Fresnel reflectance R as probability (R = 1 under total internal reflection) and
+    refracted by Snell's law otherwise; the multiplier is 1 either way.  The reference draws
+    ``torch.rand_like``; the kernels draw Philox4x32-10 uniforms from a key this functor takes from
+    torch's default generator each time a surface record is packed (reproducible under
+    ``torch.manual_seed``, fresh for every trace)."""
+    _phys_kind = P.PHYS_FRESNEL
+
+    def _fill_physics(self, rec):
+        super()._fill_physics(rec)
+        rec["phys_kind"] = self._phys_kind
+        key = int(torch.randint(0, 2 ** 62, (1,)).item())
+        rec["seed"][:] = (key & 0xFFFFFFFF, key >> 32)
+
+
+class Linear(SurfaceFunction):
+    """Paraxial surface (phys/std.py:35-88): with the incoming direction expressed in the functor's frame
+    and scaled to unit z, the outgoing slopes are (Cx x + Dx dx, Cy y + Dy dy); the result is normalised
+    and rotated back.  ``transform`` supplies the frame (LinearElement installs the surface's own)."""
+    _phys_kind = P.PHYS_LINEAR
+
+    def __init__(self, Cx: float = 0, Cy: float = 0, Dx: float = 1, Dy=1, Cx_grad=False, Cy_grad=False,
+                 Dx_grad=False, Dy_grad=False, transform=None):
+        super().__init__()
+        from ..geom.transform import RayTransform
+        mk = lambda v, g: nn.Parameter(torch.as_tensor(v, dtype=torch.float32), requires_grad=g)
+        self.Cx, self.Cy = mk(Cx, Cx_grad), mk(Cy, Cy_grad)
+        self.Dx, self.Dy = mk(Dx, Dx_grad), mk(Dy, Dy_grad)
+        self.transform = RayTransform() if transform is None else transform
+        self._rot_is_surface = False   # set by LinearElement: rotate with the surface record's own Rj
+
+    def _fill_physics(self, rec):
+        rec["phys_kind"] = self._phys_kind
+        rec["phys"][:] = (P.scalar(self.Cx), P.scalar(self.Cy), P.scalar(self.Dx), P.scalar(self.Dy))
+        if self._rot_is_surface:
+            rec["flags"] |= P.F_PHYS_ROT_SURF
+        else:
+            rec["phys_R"] = P.host_value(self.transform.rot).reshape(9)
+
+    def _diff_phys(self):
+        return torch.stack([self.Cx, self.Cy, self.Dx, self.Dy])

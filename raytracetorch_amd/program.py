@@ -16,7 +16,7 @@ SURFACE_DTYPE = np.dtype([
     ("flags", "<i4"), ("element_id", "<i4"), ("surface_id", "<i4"), ("sensor_slot", "<i4"),
     ("Rs", "<f4", (9,)), ("ts", "<f4", (3,)), ("Rj", "<f4", (9,)), ("tj", "<f4", (3,)),
     ("geom", "<f4", (4,)), ("bnd", "<f4", (4,)), ("shp", "<f4", (8,)), ("phys", "<f4", (4,)),
-    ("pad", "<f4", (12,)),
+    ("phys_R", "<f4", (9,)), ("seed", "<u4", (2,)), ("pad", "<f4", (1,)),
 ])
 RECORD_BYTES = SURFACE_DTYPE.itemsize
 assert RECORD_BYTES == 256
@@ -27,8 +27,8 @@ SURF_PLANE, SURF_QUADRIC, SURF_QUADRIC_ZY, SURF_CYLINDER, SURF_SPHERE, SURF_CONE
 (BND_NONE, BND_DISK, BND_RECT, BND_ELLIPSE, BND_HALF, BND_HALF_DISK, BND_SINGLE_CONE,
  BND_ALWAYS) = range(8)
 SHP_NONE, SHP_SPHERIC_FACE, SHP_SPHERIC_EDGE, SHP_CYL_FACE, SHP_CYL_EDGE = range(5)
-PHYS_TRANSMIT, PHYS_BLOCK, PHYS_REFLECT, PHYS_SNELL, PHYS_APERTURE = range(5)
-F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR = 1, 2, 4, 8, 16
+PHYS_TRANSMIT, PHYS_BLOCK, PHYS_REFLECT, PHYS_SNELL, PHYS_APERTURE, PHYS_LINEAR, PHYS_FRESNEL = range(7)
+F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR, F_PHYS_ROT_SURF = 1, 2, 4, 8, 16, 32
 
 _IDENTITY9 = np.eye(3, dtype=np.float32).reshape(9)
 f32 = np.float32
@@ -62,6 +62,7 @@ def new_record() -> np.ndarray:
     rec = np.zeros((), dtype=SURFACE_DTYPE)
     rec["Rs"] = _IDENTITY9
     rec["Rj"] = _IDENTITY9
+    rec["phys_R"] = _IDENTITY9
     rec["sensor_slot"] = -1
     return rec
 

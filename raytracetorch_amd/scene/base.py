@@ -86,9 +86,18 @@ class Scene(nn.Module):
         key = (els, tuple((p.data_ptr(), p._version) for p in plist[1]))
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
-            cached = (key, P.compile_elements(self.elements))
+            with torch.random.fork_rng(devices=[]):   # keys drawn while packing are replaced below
+                cached = (key, P.compile_elements(self.elements))
             self._prog_cache = cached
-        return cached[1]
+        prog = cached[1]
+        stochastic = prog["phys_kind"] == P.PHYS_FRESNEL
+        if stochastic.any():
+            # RefractFresnel draws new random numbers in every trace (phys/std.py:200): one key per call from
+            # torch's default generator; the kernels add the surface's position to it
+            key = int(torch.randint(0, 2 ** 62, (1,)).item())
+            prog = prog.copy()
+            prog["seed"][stochastic] = (key & 0xFFFFFFFF, key >> 32)
+        return prog
 
     def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask):
         if sens_hit is None:

@@ -22,6 +22,8 @@ def namespace_from_package(pkg):
     ns.Cylinder = pkg.geom.primitives.Cylinder
     ns.Cone = pkg.geom.primitives.Cone
     ns.SpotSizeLoss = pkg.optim.goals.SpotSizeLoss
+    ns.IdealMirror = pkg.elements.ideal.IdealMirror
+    ns.IdealCylThinLens = pkg.elements.ideal.IdealCylThinLens
     return ns
 
 
@@ -124,6 +126,14 @@ def sequential_cases(ns):
                              ns.CylindricalMirror(c1=0.03, d=0.0, transform=T(ns, -5.0, rot=[0.0, 0.1, 0.0])),
                              ns.ParabolicMirrorXZ(c1=-0.01, d=0.0, transform=T(ns, 25.0))],
                     lambda n: disk_bundle(ns, z=-2.0).sample(n), 2048),
+        # 2f -> 2f imaging through an ideal thin lens (tests/test_ideal.py:55-107 of the reference), tilted lens
+        "ideal_thin_lens": (lambda: [ns.IdealThinLens(focal=50.0, diameter=40.0, transform=T(ns, 0.0, rot=[0.02, -0.01, 0.0])),
+                                     ns.Sensor(ns.Disk(30.0, transform=T(ns, 100.0)))],
+                            lambda n: ns.PointSource(NA=0.15, ray_id=1, transform=ns.RayTransformBundle(
+                                translation=[0.5, -0.3, -100.0])).sample(n), 2048),
+        "ideal_mirror": (lambda: [ns.IdealMirror(radius_x=80.0, radius_y=120.0, transform=T(ns, 5.0)),
+                                  ns.Sensor(ns.Disk(30.0, transform=T(ns, 25.0)))],
+                         lambda n: disk_bundle(ns, radius=5.0, rot=[0.03, 0.0, 0.0]).sample(n), 1024),
         "cyl_singlet": (lambda: [ns.CylSingletLens(c1=0.04, c2=-0.03, height=12.0, width=10.0, t=2.5,
                                                    ior_glass=1.5, inked=False, transform=T(ns, 0.0, rot=[0.0, 0.0, 0.2]))],
                         lambda n: disk_bundle(ns, radius=7.5, rot=[0.05, 0.02, 0.0]).sample(n), 4096),
@@ -223,4 +233,26 @@ def bundle_cases(ns):
         "fan": (lambda: ns.Fan(angle=0.6, ray_id=4, transform=pose()), 3, lambda b: (-0.3, 0.3), 1),
         "point": (lambda: ns.PointSource(NA=0.25, ray_id=5, transform=pose()), 4,
                   lambda b: (0.0, float(b.F_phi_max), 0.0, 2 * math.pi), 2),
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+# physics functors called on their own (phys/std.py): name -> (constructor, inputs(n) -> (hit_local, dir, normal))
+# ---------------------------------------------------------------------------------------------
+def physics_cases(ns):
+    def unit(v):
+        return v / v.norm(dim=1, keepdim=True)
+
+    def inputs(n):
+        hl = torch.randn(n, 3) * 3.0
+        d = unit(torch.randn(n, 3) * torch.tensor([1.0, 1.0, 0.6]) + torch.tensor([0.0, 0.0, 0.8]))
+        nrm = unit(torch.randn(n, 3) * 0.5 + torch.tensor([0.0, 0.0, -1.0]))
+        return hl, d, nrm
+
+    return {
+        "fresnel_air_glass": (lambda: ns.RefractFresnel(ior_in=1.0, ior_out=1.5), inputs),
+        "fresnel_glass_air": (lambda: ns.RefractFresnel(ior_in=1.5, ior_out=1.0), inputs),   # total internal reflection occurs
+        "linear_posed": (lambda: ns.Linear(Cx=-0.02, Cy=-0.03, Dx=1.0, Dy=0.9,
+                                           transform=ns.RayTransform(rotation=[0.1, 0.05, -0.2])), inputs),
+        "linear_plain": (lambda: ns.Linear(Cx=-0.05, Cy=-0.05), inputs),
     }

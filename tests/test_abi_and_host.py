@@ -213,8 +213,9 @@ def test_constructor_validation(ns):
         ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=0.0, ior_glass=1.5)
     with pytest.raises(ValueError, match="ntersect"):
         ns.SingletLens(c1=0.15, c2=-0.15, d=10.0, t=0.5, ior_glass=1.5)
-    with pytest.raises(NotImplementedError):
-        ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5, fresnel=True)
+    fres = ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5, fresnel=True)
+    assert [type(f).__name__ for f in fres.surface_functions] == ["RefractFresnel"] * 3   # elements/lens.py:36-56
+    assert int(fres._record(0)["phys_kind"]) == P.PHYS_FRESNEL
     too_many = [scenes.singlet(ns) for _ in range(22)]
     with pytest.raises(ValueError, match="at most"):
         P.compile_elements(too_many)

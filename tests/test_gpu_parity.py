@@ -24,7 +24,7 @@ PRIMS = ["plane_c1", "plane_posed", "sphere", "cylinder", "quadric_parabola", "q
          "ellipse", "kat_plane", "kat_sphere", "kat_parabola", "kat_implicit"]
 SEQ = ["singlet", "singlet_tilted_bundle", "singlet_decentred_bundle", "singlet_posed", "singlet_plano",
        "singlet_clear_edge", "singlet_tir", "singlet_sensor", "system5", "doublet", "triplet", "dead_rays",
-       "aperture_plain", "aperture_invert", "mirrors", "cyl_singlet"]
+       "aperture_plain", "aperture_invert", "mirrors", "cyl_singlet", "ideal_thin_lens", "ideal_mirror"]
 
 
 def cpu(t):
@@ -107,16 +107,21 @@ def test_sequential_trace(ns, name):
     for f, got in (("pos", r.pos), ("dir", r.dir), ("intensity", r.intensity)):
         assert_parity(cpu(got), g[f"out_{f}"], o64[f].numpy(), what=f"{name} out {f}")
     assert torch.equal(r.id.cpu(), torch.from_numpy(g["out_id"]))
-    # sensor hit lists, in ray order
+    # sensor hit lists, in ray order (float64 evaluation of the same records as the tie-breaker for hit points
+    # whose local coordinates are small differences of large global ones)
+    truth64 = [hl[mask].numpy() for _, mask, hl, _ in o64["sensor"]]
+    slot = -1
     for k, e in enumerate(elements):
         if not hasattr(e, "getHitsTensors"):
             continue
+        slot += 1
         if f"sensor_{k}_locs" not in g:
             assert not e.hitLocs
             continue
         locs, w, ids = e.getHitsTensors()
         assert locs.shape == g[f"sensor_{k}_locs"].shape
-        assert_parity(cpu(locs), g[f"sensor_{k}_locs"], what=f"{name} sensor locs")
+        t64 = truth64[slot] if slot < len(truth64) and truth64[slot].shape == g[f"sensor_{k}_locs"].shape else None
+        assert_parity(cpu(locs), g[f"sensor_{k}_locs"], t64, what=f"{name} sensor locs")
         assert_parity(cpu(w), g[f"sensor_{k}_w"], what=f"{name} sensor w")
         assert np.array_equal(cpu(ids), g[f"sensor_{k}_id"])
     # agreement with the CPU oracle on the same program (tighter than the golden tolerance is not

@@ -1,0 +1,123 @@
+"""RefractFresnel and Linear (phys/std.py:35-88, 148-219 of the reference) and the ideal elements built on
+Linear (elements/ideal.py).
+
+CPU: the oracle reproduces the reference functors (goldens ``phys_*.npz``; Fresnel is fed the torch.rand
+values the reference consumed).  GPU: the kernels agree with the oracle given the same Philox key, the
+stochastic choice has the reference's statistics, and the known answers of the reference's tests/test_ideal.py
+(2f -> 2f imaging, magnification -1) hold.
+"""
+import numpy as np
+import pytest
+import torch
+
+import rtt_oracle as O
+import scenes
+from util import PARITY_TOL, golden, rel_err
+
+import raytracetorch_amd.program as P
+
+PHYS = ["fresnel_air_glass", "fresnel_glass_air", "linear_posed", "linear_plain"]
+DEV = "cuda:0"
+
+
+def _record(fn):
+    rec = P.new_record()
+    fn._fill_physics(rec)
+    return rec
+
+
+@pytest.mark.parametrize("name", PHYS)
+def test_oracle_functor_matches_reference(ns, name):
+    g = golden("phys_" + name)
+    fn = scenes.physics_cases(ns)[name][0]()
+    S = O._records(_record(fn)[None], torch.float32)[0]
+    hl, d, n = (torch.from_numpy(g[k]) for k in ("hit_local", "dir", "normal"))
+    nd, im = O.apply_physics(S, hl, d, n, u=g["u"])
+    assert rel_err(nd.numpy(), g["new_dir"]) < 2e-6
+    assert np.array_equal(im.numpy(), g["imult"])
+    if name == "fresnel_glass_air":
+        # the case exercises both branches: some rays reflect (incl. total internal reflection), some refract
+        refl = np.abs((g["new_dir"] * g["normal"]).sum(1) + (g["dir"] * g["normal"]).sum(1)) < 1e-5
+        assert 0.05 < refl.mean() < 0.95
+
+
+def test_ideal_cyl_thin_lens_constructor_raises_like_the_reference(ns):
+    with pytest.raises(IndexError):   # elements/ideal.py:108 indexes a functor that does not exist
+        ns.IdealCylThinLens(focal_x=10.0, focal_y=20.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PHYS)
+def test_device_functor_matches_oracle(ns, name):
+    g = golden("phys_" + name)
+    fn = scenes.physics_cases(ns)[name][0]()
+    hl, d, n = (torch.from_numpy(g[k]) for k in ("hit_local", "dir", "normal"))
+    torch.manual_seed(5)
+    S = O._records(_record(fn)[None], torch.float32)[0]       # draws the Philox key the call below will draw
+    torch.manual_seed(5)
+    got_d, got_m = fn(hl.to(DEV), d.to(DEV), n.to(DEV))
+    want_d, want_m = O.apply_physics(S, hl, d, n)
+    # rays whose uniform lies within rounding of the reflectance may legitimately flip: none expected at 4096
+    assert rel_err(got_d.cpu().numpy(), want_d.numpy()) < PARITY_TOL
+    assert np.array_equal(got_m.cpu().numpy(), want_m.numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fresnel_air_glass", "fresnel_glass_air"])
+def test_fresnel_reflected_fraction_matches_reference(ns, name):
+    g = golden("phys_" + name)
+    fn = scenes.physics_cases(ns)[name][0]()
+    reps = 64
+    hl, d, n = (torch.from_numpy(np.tile(g[k], (reps, 1))).to(DEV) for k in ("hit_local", "dir", "normal"))
+    torch.manual_seed(9)
+    got_d, _ = fn(hl, d, n)
+    is_refl = lambda nd, dd, nn: np.abs((nd * nn).sum(1) + (dd * nn).sum(1)) < 1e-5   # mirror law
+    got = is_refl(got_d.cpu().numpy(), d.cpu().numpy(), n.cpu().numpy()).reshape(reps, -1)
+    ref = is_refl(g["new_dir"], g["dir"], g["normal"])
+    # per-ray reflection frequency over 64 draws vs the reference's single draw: means agree within sampling error
+    p = got.mean(0)
+    sigma = np.sqrt((p * (1 - p)).sum()) / len(p) + 1e-9
+    assert abs(p.mean() - ref.mean()) < 5 * sigma + 2e-3
+    # deterministic rays (R = 1 under total internal reflection) agree ray by ray
+    sure = p == 1.0
+    assert ref[sure].all()
+
+
+@pytest.mark.gpu
+def test_fresnel_lens_trace_matches_oracle(ns):
+    """A singlet with fresnel=True in a sequential trace: every ray takes the branch the oracle takes under
+    the same per-trace key, and a sensible fraction of the bundle is reflected."""
+    lens = scenes.singlet(ns, fresnel=True, inked=True)
+    scene = ns.SequentialScene([lens])
+    torch.manual_seed(0)
+    rays = scenes.disk_bundle(ns).sample(1 << 14).to(DEV)
+    src = rays.clone()
+    torch.manual_seed(21)
+    prog = scene._program()
+    torch.manual_seed(21)
+    out = scene.simulate(rays)
+    ref = O.trace_sequential(prog, src.pos.cpu(), src.dir.cpu(), src.intensity.cpu())
+    assert rel_err(out.pos.cpu().numpy(), ref["pos"].numpy()) < PARITY_TOL
+    assert rel_err(out.dir.cpu().numpy(), ref["dir"].numpy()) < PARITY_TOL
+    back = (out.dir.cpu().numpy()[:, 2] < 0).mean()
+    assert 0.01 < back < 0.2      # ~4 % per air/glass face at near-normal incidence
+    # a second trace draws a new key: different rays reflect
+    again = scene.simulate(src.clone())
+    assert not torch.equal(again._dir, out._dir)
+
+
+@pytest.mark.gpu
+def test_ideal_thin_lens_known_answers(ns):
+    """tests/test_ideal.py:55-107 of the reference: a point 2f in front of an ideal thin lens images 2f behind
+    it with magnification -1 (tolerance of the reference's test: 0.1 on the mean, 1e-3 on the spread)."""
+    f = 50.0
+    lens = ns.IdealThinLens(focal=f)
+    sensor = ns.Sensor(ns.Disk(100.0, transform=ns.RayTransform(translation=[0.0, 0.0, 2 * f])))
+    scene = ns.SequentialScene([lens, sensor])
+    src = ns.PointSource(NA=0.1, ray_id=0, device=DEV,
+                         transform=ns.RayTransformBundle(translation=[1.0, -2.0, -2 * f]).to(DEV))
+    scene.simulate(src.sample(4096, seed=1))
+    hits = sensor.getHitsTensors()[0].cpu().numpy()
+    assert hits.shape[0] == 4096
+    assert np.abs(hits[:, :2].mean(0) - np.array([-1.0, 2.0])).max() < 0.1
+    assert hits[:, :2].std(0).max() < 1e-3
