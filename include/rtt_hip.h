@@ -60,7 +60,11 @@ enum {
   RTT_SHP_SPHERIC_FACE = 1, /* x^2+y^2 <= shp[0]                       spherics.py:40-46    */
   RTT_SHP_SPHERIC_EDGE = 2, /* shp[0] <= z <= shp[1]                   spherics.py:34-39    */
   RTT_SHP_CYL_FACE = 3,     /* box aperture shp[0..3]                  cylindrics.py:31-42  */
-  RTT_SHP_CYL_EDGE = 4      /* box & sag(y) limits, shp[4..7]=c0,tz0,c1,tz1 cylindrics.py:44-55 */
+  RTT_SHP_CYL_EDGE = 4,     /* box & sag(y) limits, shp[4..7]=c0,tz0,c1,tz1 cylindrics.py:44-55 */
+  RTT_SHP_POLYHEDRON = 5    /* CvxPolyhedron: n_q . (hit - t_q) < 1e-4 for every other plane q of the element,
+                               n_q = row 2 of Rj_q, t_q = tj_q, read from the element's own records: the
+                               shp[0] records of one polyhedron are consecutive in the program and ordered by
+                               surface_id                                   shape.py:104-132 */
 };
 
 /* surface physics (phys/std.py, phys/filter.py) */

@@ -33,7 +33,7 @@ assert SURFACE_DTYPE.itemsize == 256
 
 PLANE, QUADRIC, QUADRIC_ZY, CYLINDER, SPHERE, CONE = range(6)
 B_NONE, B_DISK, B_RECT, B_ELLIPSE, B_HALF, B_HALF_DISK, B_SINGLE_CONE, B_ALWAYS = range(8)
-S_NONE, S_SPHERIC_FACE, S_SPHERIC_EDGE, S_CYL_FACE, S_CYL_EDGE = range(5)
+S_NONE, S_SPHERIC_FACE, S_SPHERIC_EDGE, S_CYL_FACE, S_CYL_EDGE, S_POLYHEDRON = range(6)
 P_TRANSMIT, P_BLOCK, P_REFLECT, P_SNELL, P_APERTURE, P_LINEAR, P_FRESNEL = range(7)
 F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR, F_PHYS_ROT_SURF = 1, 2, 4, 8, 16, 32
 
@@ -202,6 +202,15 @@ def shape_in_bounds(S, he):
         zb = _sag(S.shp[6], S.shp[7], y)
         in_z = (z >= zf + 1e-4) & (z <= zb - 1e-4)
         return in_z & ap
+    if k == S_POLYHEDRON:  # geom/shape.py:122-132; S.siblings = the element's plane records in surface order
+        inside = torch.ones_like(x, dtype=torch.bool)
+        for q, Q in enumerate(S.siblings):
+            if q == S.surface_id:
+                continue
+            nq, tq = Q.Rj[2, :], Q.tj
+            lz = nq[0] * (x - tq[0]) + nq[1] * (y - tq[1]) + nq[2] * (z - tq[2])
+            inside = inside & (lz < 1e-4)
+        return inside
     raise ValueError(f"shape_in_bounds on shape kind {k}")
 
 
@@ -374,7 +383,12 @@ def element_forward(S, p, d):
 def _records(prog, dtype):
     prog = np.asarray(prog)
     assert prog.dtype == SURFACE_DTYPE
-    return [_Rec(prog[i], dtype) for i in range(prog.shape[0])]
+    recs = [_Rec(prog[i], dtype) for i in range(prog.shape[0])]
+    for i, S in enumerate(recs):
+        if S.shape_kind == S_POLYHEDRON:
+            first = i - S.surface_id
+            S.siblings = recs[first:first + int(S.shp[0])]
+    return recs
 
 
 def _as(x, dtype):

@@ -619,6 +619,20 @@ DI typename LaneOf<T>::M shape_in_bounds(const RV& S, V3<T> h) {
       const T zb = sag(S.shp(6), S.shp(7), h.y);
       return and_(and_(ge(h.z, zf + 1e-4f), le(h.z, zb - 1e-4f)), ap);
     }
+    case RTT_SHP_POLYHEDRON: {  // geom/shape.py:122-132
+      // the planes are the element's own records, which sit next to this one in the program (checked on the
+      // host); the loop and the record reads are wave-uniform
+      const RttSurface* first = &S.r - S.r.surface_id;
+      const int count = (int)S.r.shp[0];
+      auto inside = mask_all<typename LaneOf<T>::M>(true);
+      for (int q = 0; q < count; ++q) {
+        if (q == S.r.surface_id) continue;
+        const RttSurface& Q = first[q];
+        const T z = Q.Rj[6] * (h.x - Q.tj[0]) + Q.Rj[7] * (h.y - Q.tj[1]) + Q.Rj[8] * (h.z - Q.tj[2]);
+        inside = and_(inside, lt(z, splat<T>(1e-4f)));
+      }
+      return inside;
+    }
     default:
       return mask_all<typename LaneOf<T>::M>(true);
   }
@@ -1519,7 +1533,7 @@ Ops make_ops(const RttSurface* host, int n_surf) {
   return ops;
 }
 
-int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_slots) {
+int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_slots, bool with_siblings = true) {
   if (n_surf < 1 || n_surf > RTT_MAX_SURFACES) return RTT_E_SIZE;
   if (any_sensor) *any_sensor = false;
   if (n_slots) *n_slots = 0;
@@ -1528,7 +1542,14 @@ int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_s
     const RttSurface& S = host[s];
     if (S.surf_kind < RTT_SURF_PLANE || S.surf_kind > RTT_SURF_CONE) return RTT_E_KIND;
     if (S.bound_kind < RTT_BND_NONE || S.bound_kind > RTT_BND_ALWAYS) return RTT_E_KIND;
-    if (S.shape_kind < RTT_SHP_NONE || S.shape_kind > RTT_SHP_CYL_EDGE) return RTT_E_KIND;
+    if (S.shape_kind < RTT_SHP_NONE || S.shape_kind > RTT_SHP_POLYHEDRON) return RTT_E_KIND;
+    if (S.shape_kind == RTT_SHP_POLYHEDRON && with_siblings) {
+      // the shape bound reads the sibling records first .. first + count - 1: they must exist in this program
+      const int count = (int)S.shp[0], first = s - S.surface_id;
+      if (count < 1 || S.surface_id < 0 || S.surface_id >= count || first < 0 || first + count > n_surf) return RTT_E_SIZE;
+      for (int q = 0; q < count; ++q)
+        if (host[first + q].element_id != S.element_id || host[first + q].surface_id != q) return RTT_E_KIND;
+    }
     if (S.phys_kind < RTT_PHYS_TRANSMIT || S.phys_kind > RTT_PHYS_FRESNEL) return RTT_E_KIND;
     if ((S.shape_kind != RTT_SHP_NONE) != ((S.flags & RTT_F_HAS_SHAPE) != 0)) return RTT_E_KIND;
     if ((S.flags & RTT_F_SENSOR) && any_sensor) {  // slots only matter to entry points that record
@@ -1707,7 +1728,7 @@ int rtt_surface_forward_f32(const float* pos, const float* dir, int64_t ld, int6
       misaligned(normal_global) || misaligned(hit_local) || misaligned(new_dir) || misaligned(imult))
     return RTT_E_ALIGN;
   if (prog_host) {
-    int rc = check_program(prog_host + surf_index, 1, nullptr, nullptr);
+    int rc = check_program(prog_host + surf_index, 1, nullptr, nullptr, false);  // forward applies no shape bound
     if (rc != RTT_OK) return rc;
   }
   if (n == 0) return RTT_OK;

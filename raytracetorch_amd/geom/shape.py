@@ -75,13 +75,19 @@ def _axis_plane(pos, rot_vec, optimize_flag):
 
 
 class CvxPolyhedron(Shape):
-    """Intersection of half-spaces z_q < 1e-4 of its planes (geom/shape.py:104-132).  Kept as a
-    container of planes; as a traced shape of its own it has no kernel description yet."""
+    """Intersection of half-spaces z_q < 1e-4 of its planes (geom/shape.py:104-132).  In a trace the bound
+    of surface j is evaluated from the records of the element's other planes, which the scene compiler
+    places next to it (shape kind ``SHP_POLYHEDRON``)."""
 
     def __init__(self, planes_list=None, transform: Optional[RayTransform] = None):
         super().__init__(transform=transform)
         for s in planes_list or ():
             self.surfaces.append(s)
+
+    def _fill_shape_bound(self, rec, j: int):
+        rec["shape_kind"] = P.SHP_POLYHEDRON
+        rec["surface_id"] = j
+        rec["shp"][0] = len(self.surfaces)
 
     @property
     def PlaneRotMat(self):

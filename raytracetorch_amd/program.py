@@ -26,7 +26,7 @@ MAX_SURFACES = 64
 SURF_PLANE, SURF_QUADRIC, SURF_QUADRIC_ZY, SURF_CYLINDER, SURF_SPHERE, SURF_CONE = range(6)
 (BND_NONE, BND_DISK, BND_RECT, BND_ELLIPSE, BND_HALF, BND_HALF_DISK, BND_SINGLE_CONE,
  BND_ALWAYS) = range(8)
-SHP_NONE, SHP_SPHERIC_FACE, SHP_SPHERIC_EDGE, SHP_CYL_FACE, SHP_CYL_EDGE = range(5)
+SHP_NONE, SHP_SPHERIC_FACE, SHP_SPHERIC_EDGE, SHP_CYL_FACE, SHP_CYL_EDGE, SHP_POLYHEDRON = range(6)
 PHYS_TRANSMIT, PHYS_BLOCK, PHYS_REFLECT, PHYS_SNELL, PHYS_APERTURE, PHYS_LINEAR, PHYS_FRESNEL = range(7)
 F_HAS_SHAPE, F_SHAPE_ROT_ID, F_SURF_ROT_ID, F_INVERT, F_SENSOR, F_PHYS_ROT_SURF = 1, 2, 4, 8, 16, 32
 

@@ -22,6 +22,7 @@ def namespace_from_package(pkg):
     ns.Cylinder = pkg.geom.primitives.Cylinder
     ns.Cone = pkg.geom.primitives.Cone
     ns.SpotSizeLoss = pkg.optim.goals.SpotSizeLoss
+    ns.ElementCustom = pkg.elements.parent.ElementCustom
     ns.IdealMirror = pkg.elements.ideal.IdealMirror
     ns.IdealCylThinLens = pkg.elements.ideal.IdealCylThinLens
     return ns
@@ -134,6 +135,12 @@ def sequential_cases(ns):
         "ideal_mirror": (lambda: [ns.IdealMirror(radius_x=80.0, radius_y=120.0, transform=T(ns, 5.0)),
                                   ns.Sensor(ns.Disk(30.0, transform=T(ns, 25.0)))],
                          lambda n: disk_bundle(ns, radius=5.0, rot=[0.03, 0.0, 0.0]).sample(n), 1024),
+        # convex polyhedron as a traced shape: a posed reflecting box, then a refracting one
+        "box": (lambda: [ns.ElementCustom(ns.Box(length=6.0, width=4.0, height=5.0,
+                                                 transform=T(ns, 2.0, x=0.5, rot=[0.3, -0.4, 0.1])), ns.Reflect(), None),
+                         ns.ElementCustom(ns.Box(length=3.0, width=8.0, height=8.0, transform=T(ns, -12.0, rot=[0.0, 0.2, 0.0])),
+                                          ns.RefractSnell(1.0, 1.5), None)],
+                lambda n: disk_bundle(ns, radius=4.5, rot=[0.05, -0.02, 0.0]).sample(n), 2048),
         "cyl_singlet": (lambda: [ns.CylSingletLens(c1=0.04, c2=-0.03, height=12.0, width=10.0, t=2.5,
                                                    ior_glass=1.5, inked=False, transform=T(ns, 0.0, rot=[0.0, 0.0, 0.2]))],
                         lambda n: disk_bundle(ns, radius=7.5, rot=[0.05, 0.02, 0.0]).sample(n), 4096),

@@ -24,7 +24,7 @@ PRIMS = ["plane_c1", "plane_posed", "sphere", "cylinder", "quadric_parabola", "q
          "ellipse", "kat_plane", "kat_sphere", "kat_parabola", "kat_implicit"]
 SEQ = ["singlet", "singlet_tilted_bundle", "singlet_decentred_bundle", "singlet_posed", "singlet_plano",
        "singlet_clear_edge", "singlet_tir", "singlet_sensor", "system5", "doublet", "triplet", "dead_rays",
-       "aperture_plain", "aperture_invert", "mirrors", "cyl_singlet", "ideal_thin_lens", "ideal_mirror"]
+       "aperture_plain", "aperture_invert", "mirrors", "cyl_singlet", "ideal_thin_lens", "ideal_mirror", "box"]
 
 
 def cpu(t):

@@ -54,7 +54,7 @@ def test_reference_known_answers(ns):
 
 SEQ = ["singlet", "singlet_tilted_bundle", "singlet_decentred_bundle", "singlet_posed", "singlet_plano",
        "singlet_clear_edge", "singlet_tir", "singlet_sensor", "system5", "doublet", "triplet", "dead_rays",
-       "aperture_plain", "aperture_invert", "mirrors", "cyl_singlet", "ideal_thin_lens", "ideal_mirror"]
+       "aperture_plain", "aperture_invert", "mirrors", "cyl_singlet", "ideal_thin_lens", "ideal_mirror", "box"]
 
 
 @pytest.mark.parametrize("name", SEQ)
