@@ -119,6 +119,17 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
                       float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
                       void* stream);
 
+/* ---- the same trace with per-surface position snapshots: SequentialScene.simulate on rays wrapped in Paths
+ * (rays/ray.py:100-207; Paths.scatter_update :174-185 snapshots every ray's position after each surface that
+ * was hit by at least one ray).  hist_pos[(3*s + c)*hist_ld + i] receives component c of ray i after surface s,
+ * hist_any[s] (zeroed by the caller) is set to 1 when some ray hit surface s.  A visualisation aid: one ray per
+ * lane, not tuned. */
+int rtt_trace_seq_history_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                              float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
+                              float* hist_pos, int32_t* hist_any, int64_t hist_ld, void* stream);
+
 /* ---- backward of the sequential trace w.r.t. scene parameters (what torch autograd does to
  * scene/sequential.py:12-36 when c, k, trans, rot_vec, ior_* carry requires_grad; reached in the
  * reference through optim/goals.py:144-187 and tests/test_optimize_singlet.py:66-116).

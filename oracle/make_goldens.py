@@ -203,6 +203,25 @@ def gen_bundles(ns):
         print("bundle", name, tuple(rays.pos.shape))
 
 
+def gen_paths(ns):
+    """Paths history (rays/ray.py:100-207) of the first bounce of a small nearest-hit scene.  (The reference's
+    SequentialScene cannot take a Paths wrapper: Shape.intersectTest calls rays.with_coords, which Paths lacks.)"""
+    torch.manual_seed(0)
+    rays = scenes.disk_bundle(ns, radius=6.0).sample(1024)
+    out = rays_arrays(rays, "in_")
+    scene = ns.Scene()
+    for el in [scenes.singlet(ns), ns.Sensor(ns.Disk(20.0, transform=scenes.T(ns, 19.0)))]:
+        scene.add_element(el)
+    scene._build_index_maps()
+    scene.rays = ns.Paths(clone_rays(ns, rays))
+    with torch.no_grad():
+        scene.step()
+    out["step_history"] = np.stack([npy(h) for h in scene.rays.get_history()])
+    out.update(rays_arrays(scene.rays.unwrap(), "step1_"))
+    np.savez_compressed(os.path.join(OUT, "paths.npz"), **out)
+    print("paths", out["step_history"].shape)
+
+
 def gen_physics(ns):
     """Functors called directly.  RefractFresnel consumes torch.rand_like(R) ([N,1]) once per call; the same
     values are recorded by re-seeding."""
@@ -229,6 +248,8 @@ def main():
         return gen_bundles(ns)
     if sys.argv[1:] == ["physics"]:
         return gen_physics(ns)
+    if sys.argv[1:] == ["paths"]:
+        return gen_paths(ns)
     if sys.argv[1:2] == ["seq"]:
         return gen_sequential(ns, only=sys.argv[2:])
     gen_primitives(ns)
@@ -239,6 +260,7 @@ def main():
     gen_grad_kats(ns)
     gen_bundles(ns)
     gen_physics(ns)
+    gen_paths(ns)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@ _dbl = ctypes.c_double
 _SIGNATURES = {
     "rtt_trace_seq_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                           _vp, _vp, _vp, _i64, _vp],
+    "rtt_trace_seq_history_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
+                                  _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
     "rtt_trace_seq_tangent_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64,
                                   _vp, _vp],
     "rtt_trace_seq_spot_grad_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _int, _int, _dbl, _dbl, _dbl,

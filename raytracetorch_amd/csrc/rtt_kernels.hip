@@ -1023,6 +1023,31 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
   }
 }
 
+// The same trace with the position of every ray recorded after each surface (the per-bounce snapshots a
+// Paths wrapper keeps, rays/ray.py:174-185): a visualisation aid, one ray per lane, generic visits.
+// hist[(3 s + c) * hist_ld + i] = component c of ray i after surface s; hist_any[s] = 1 when any ray hit s.
+__global__ void __launch_bounds__(kBlock) k_trace_seq_history(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
+                                                              SensorIO se, float* __restrict__ hist,
+                                                              int32_t* __restrict__ hist_any, int64_t hist_ld) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
+    Ray<float> r = load_ray<float>(io, i);
+    for (int s = 0; s < n_surf; ++s) {
+      const RecF S{prog[s]};
+      Frames<float> f;
+      float t_raw;
+      const bool hit = test_surface<CGeneric>(S, r.p, r.d, f, t_raw);
+      interact<CGeneric>(S, f, t_raw, hit, r, se, i, 1);
+      float* h = hist + (int64_t)3 * s * hist_ld + i;
+      h[0] = r.p.x;
+      h[hist_ld] = r.p.y;
+      h[2 * hist_ld] = r.p.z;
+      if (hit) hist_any[s] = 1;  // every writer stores the same value
+    }
+    store_ray<float>(io, i, r);
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
@@ -1761,6 +1786,31 @@ int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const u
   if (n == 0) return RTT_OK;
   hipLaunchKernelGGL(k_spot_moments, dim3(grid_for_reduction(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w, mask, n,
                      pass, cx, cy, wsum, out);
+  return launch_status();
+}
+
+int rtt_trace_seq_history_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, float* sens_hit,
+                              float* sens_w, uint8_t* sens_mask, int64_t sens_ld, float* hist_pos, int32_t* hist_any,
+                              int64_t hist_ld, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !hist_pos || !hist_any)
+    return RTT_E_NULL;
+  if (n < 0 || ld_in < n || ld_out < n || hist_ld < n) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out) || misaligned(sens_hit) || misaligned(sens_w) || misaligned(hist_pos) || misaligned(hist_any))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (!prog_host) any_sensor = sens_hit != nullptr;
+  if (any_sensor && (!sens_hit || !sens_w || !sens_mask)) return RTT_E_NULL;
+  if (any_sensor && sens_ld < n) return RTT_E_SIZE;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+  SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld, 0};
+  hipLaunchKernelGGL(k_trace_seq_history, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev, n_surf, se,
+                     hist_pos, hist_any, hist_ld);
   return launch_status();
 }
 

@@ -58,6 +58,28 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None):
     return sens_hit, sens_w, sens_mask
 
 
+def trace_sequential_history(rays: Rays, prog: np.ndarray):
+    """SequentialScene.simulate in place plus the position of every ray after each surface.
+    Returns (sens_hit, sens_w, sens_mask, hist [S,3,N], hit_any [S] int32)."""
+    n = _check_rays(rays)
+    dev = rays.device
+    s = prog.shape[0]
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev)
+    hist = torch.empty((s, 3, n), device=dev, dtype=torch.float32)
+    hit_any = torch.zeros((s,), device=dev, dtype=torch.int32)
+    if n and s:
+        dp = N.DeviceProgram.upload(prog, dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_trace_seq_history_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n,
+                N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n,
+                N.ptr(hist), N.ptr(hit_any), n, N.stream_handle(dev))
+        N.check(code, "rtt_trace_seq_history_f32")
+    return sens_hit, sens_w, sens_mask, hist, hit_any
+
+
 def intersect_test(rays: Rays, prog: np.ndarray) -> torch.Tensor:
     """[N, S] matrix of distances (inf = miss), returned as a transposed view of [S, N] planes."""
     n = _check_rays(rays)

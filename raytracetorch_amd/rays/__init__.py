@@ -1,2 +1,2 @@
-from .ray import Rays
+from .ray import Rays, Paths
 from .bundle import Bundle, DiskSample, SolidAngleSample, CollimatedDisk, CollimatedLine, Fan, PointSource

@@ -131,3 +131,47 @@ class Rays:
 
     def __repr__(self):
         return f"Rays(N={len(self)}, device={self.device}, layout=planes[3,N])"
+
+
+class Paths:
+    """Proxy around ``Rays`` that keeps the position of every ray after each update, for visualisation
+    (rays/ray.py:100-207).  ``Scene.step`` and ``SequentialScene.simulate`` recognise the wrapper: a bounce of
+    the nearest-hit tracer adds one snapshot, a sequential trace adds one per surface that was hit
+    (``rtt_trace_seq_history_f32``), as the reference's per-surface ``scatter_update`` calls do."""
+
+    def __init__(self, rays: Rays):
+        self._rays = rays
+        self._history = [rays.pos.clone().detach().cpu()]
+
+    pos = property(lambda self: self._rays.pos, lambda self, v: setattr(self._rays, "pos", v))
+    dir = property(lambda self: self._rays.dir, lambda self, v: setattr(self._rays, "dir", v))
+    intensity = property(lambda self: self._rays.intensity, lambda self, v: setattr(self._rays, "intensity", v))
+    id = property(lambda self: self._rays.id)
+    wavelength = property(lambda self: self._rays.wavelength)
+    batch_size = property(lambda self: self._rays.batch_size)
+    device = property(lambda self: self._rays.device)
+
+    def __len__(self):
+        return len(self._rays)
+
+    def __getitem__(self, idx):
+        return self._rays[idx]
+
+    def _snapshot(self, planes=None):
+        src = self._rays._pos if planes is None else planes
+        self._history.append(src.t().clone().detach().cpu())
+
+    def scatter_update(self, mask, new_pos, new_dir, intensity_mod):
+        self._rays.scatter_update(mask, new_pos, new_dir, intensity_mod)
+        self._snapshot()
+
+    def unwrap(self) -> Rays:
+        return self._rays
+
+    def get_history(self) -> list:
+        """[N, 3] CPU tensors: the initial positions, then one snapshot per recorded update."""
+        return self._history
+
+    def to(self, device):
+        self._rays = self._rays.to(device)
+        return self

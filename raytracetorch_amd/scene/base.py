@@ -144,8 +144,12 @@ class Scene(nn.Module):
             return
         raw = self.rays.unwrap() if hasattr(self.rays, "unwrap") else self.rays
         prog = self._program()
-        _, sens_hit, sens_w, sens_mask = K.step_nearest(raw, prog)
+        recording = raw is not self.rays and hasattr(self.rays, "_snapshot")   # rays wrapped in Paths
+        lit = raw.intensity > 0 if recording else None
+        winner, sens_hit, sens_w, sens_mask = K.step_nearest(raw, prog, want_winner=recording)
         self._deliver_sensor_records(prog, raw, sens_hit, sens_w, sens_mask)
+        if recording and bool(((winner >= 0) & lit).any()):
+            self.rays._snapshot()   # one snapshot per bounce that moved a ray (scene/base.py:201-235)
 
     def compile_elements(self):
         """The reference wraps elements in torch.compile here (scene/base.py:237-255); the HIP

@@ -22,6 +22,15 @@ class SequentialScene(Scene):
         (scene/sequential.py:12-36).  With `out` (a second Rays of the same size) the result goes
         there and `rays` is left untouched."""
         prog = self._program()
+        from ..rays.ray import Paths
+        if isinstance(rays, Paths):
+            # visualisation path: in place on the wrapped rays, one snapshot per surface that was hit
+            raw = rays.unwrap()
+            sens_hit, sens_w, sens_mask, hist, hit_any = K.trace_sequential_history(raw, prog)
+            self._deliver_sensor_records(prog, raw, sens_hit, sens_w, sens_mask)
+            for s in hit_any.nonzero().flatten().tolist():
+                rays._snapshot(hist[s])
+            return rays
         from .. import autograd as AG
         if AG.needs_grad(self.elements):
             # differentiable w.r.t. the scene parameters: the backward re-traces the input bundle, whose

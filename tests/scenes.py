@@ -22,6 +22,7 @@ def namespace_from_package(pkg):
     ns.Cylinder = pkg.geom.primitives.Cylinder
     ns.Cone = pkg.geom.primitives.Cone
     ns.SpotSizeLoss = pkg.optim.goals.SpotSizeLoss
+    ns.Paths = pkg.rays.Paths
     ns.ElementCustom = pkg.elements.parent.ElementCustom
     ns.IdealMirror = pkg.elements.ideal.IdealMirror
     ns.IdealCylThinLens = pkg.elements.ideal.IdealCylThinLens

@@ -211,3 +211,44 @@ def test_physics_functors_direct(ns):
         got_d, got_m = fn(hl.to(DEV), d.to(DEV), nrm.to(DEV))
         assert rel_err(cpu(got_d), want_d.numpy()) < PARITY_TOL
         assert np.array_equal(cpu(got_m), want_m.numpy())
+
+
+def test_paths_history(ns):
+    """Paths wrapper (rays/ray.py:100-207): the first bounce of the nearest-hit tracer records the reference's
+    snapshot; a sequential trace records one snapshot per surface that was hit, equal to the prefix traces."""
+    g = golden("paths")
+    scene = ns.Scene()
+    for el in [scenes.singlet(ns), ns.Sensor(ns.Disk(20.0, transform=scenes.T(ns, 19.0)))]:
+        scene.add_element(el)
+    scene._build_index_maps()
+    scene.rays = ns.Paths(rays_from_golden(ns, g, device=DEV))
+    scene.step()
+    hist = scene.rays.get_history()
+    assert len(hist) == g["step_history"].shape[0] == 2
+    assert not hist[0].is_cuda and torch.equal(hist[0], torch.from_numpy(g["in_pos"]))
+    assert rel_err(hist[1].numpy(), g["step_history"][1]) < PARITY_TOL
+    assert rel_err(cpu(scene.rays.unwrap().pos), g["step1_pos"]) < PARITY_TOL
+    # sequential: system5 (9 surfaces); every snapshot equals the trace of the program prefix
+    elements = scenes.system5(ns)
+    seq = ns.SequentialScene(elements)
+    prog = seq._program()
+    rays0 = rays_from_golden(ns, g, device=DEV)
+    paths = ns.Paths(rays0.clone())
+    assert seq.simulate(paths) is paths
+    plain = seq.simulate(rays0.clone())
+    assert rel_err(cpu(paths.unwrap().pos), cpu(plain.pos)) < PARITY_TOL and rel_err(cpu(paths.unwrap().dir), cpu(plain.dir)) < PARITY_TOL
+    hist = paths.get_history()
+    p0, d0, I0 = g["in_pos"], g["in_dir"], g["in_intensity"]
+    hit_surfaces = [s for s in range(len(prog))
+                    if bool((O.intersect_matrix(prog[s:s + 1], *_state_before(prog, s, p0, d0, I0)) < INF).any())]
+    assert len(hist) == 1 + len(hit_surfaces)
+    for h, s in zip(hist[1:], hit_surfaces):
+        want = O.trace_sequential(prog[:s + 1], p0, d0, I0)["pos"].numpy()
+        assert rel_err(h.numpy(), want) < PARITY_TOL, s
+
+
+def _state_before(prog, s, p0, d0, I0):
+    if s == 0:
+        return p0, d0
+    o = O.trace_sequential(prog[:s], p0, d0, I0)
+    return o["pos"].numpy(), o["dir"].numpy()
