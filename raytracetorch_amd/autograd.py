@@ -238,6 +238,7 @@ class FusedSpotLossFn(torch.autograd.Function):
         _spot_moments(x, y, w, mask, 0, 0.0, 0.0, 1.0, mom)
         allreduce_sum_(mom, group)
         W, Sx, Sy, _ = mom.tolist()
+        ctx.lit = W > 0.0
         W = max(W, 1e-12)
         cx, cy = (Sx / W, Sy / W) if target is None else (float(target[0]), float(target[1]))
         mom[3] = 0.0
@@ -287,4 +288,6 @@ def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=
         if id(p) not in seen:
             seen.add(id(p))
             params.append(p)
-    return FusedSpotLossFn.apply(rays, prog, table, thetas, group, target, sensor_slot, sens, *params)
+    loss = FusedSpotLossFn.apply(rays, prog, table, thetas, group, target, sensor_slot, sens, *params)
+    # no lit hit on any rank: the reference skips such a bundle (optim/goals.py:165-167)
+    return loss if loss.grad_fn is None or loss.grad_fn.lit else None

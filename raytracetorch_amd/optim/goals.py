@@ -72,10 +72,11 @@ class SpotSizeLoss(Goal):
         scene._deliver_sensor_records(prog, src, hit, w, mask)
         rays._pos, rays._dir, rays.intensity = out._pos, out._dir, out.intensity
         k = slots[0]
-        if not bool(((w[k] > 0) & mask[k].bool()).any()):
-            return False
-        return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
+        # the host work of the backward's set-up (parameter list, slot Jacobians) runs while the device traces;
+        # "nothing lit reached the sensor" (optim/goals.py:165-167) is read off the first moment, W = 0
+        loss = AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
                                   group=getattr(scene, "grad_group", None))
+        return False if loss is None else loss
 
     def _sensor_records(self):
         s = self.sensor
