@@ -215,3 +215,26 @@ def test_launch_variants_agree(ns):
             assert lib.rtt_tune(2, 0) == 0 and lib.rtt_tune(0, 2) == 0
     finally:
         lib.rtt_tune(2, 0); lib.rtt_tune(0, 2)
+
+
+def test_simulate_is_capturable_in_a_hip_graph(ns):
+    """One SequentialScene.simulate captured in a HIP graph and replayed gives the eager result (the C side
+    neither allocates nor synchronises; the surface program is resident after the first call)."""
+    scene = ns.SequentialScene([scenes.singlet(ns)])
+    torch.manual_seed(0)
+    rays = scenes.disk_bundle(ns).sample(1 << 16).to(DEV)
+    eager = scene.simulate(rays.clone())
+    out = rays.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        scene.simulate(rays, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    out._pos.zero_(); out._dir.zero_(); out.intensity.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        scene.simulate(rays, out=out)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out._pos, eager._pos) and torch.equal(out._dir, eager._dir)
+    assert torch.equal(out.intensity, eager.intensity)
