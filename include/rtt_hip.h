@@ -172,6 +172,16 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
                          int32_t* winner, float* sens_hit, float* sens_w, uint8_t* sens_mask,
                          int64_t sens_ld, void* stream);
 
+/* ---- single-bounce shaded view: Renderer.render_3d (render/camera.py:191-257) and its colouring
+ * (render/camera.py:259-318).  Nearest hit over the surfaces whose bit in skip_mask is clear (the reference
+ * leaves aperture elements out of the competition), normal of the winner (geom/shape.py:61-87), colour =
+ * base_rgb[3*s..] * (0.3 + 0.7 |n . light_dir|) clamped to [0,1]; background where nothing is hit.
+ * base_rgb is a device array [n_surf][3]; light_dir and background are host arrays; rgb is [n][3]. */
+int rtt_render_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
+                   const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                   const float* base_rgb, uint64_t skip_mask, const float light_dir[3],
+                   const float background[3], float* rgb, void* stream);
+
 /* ---- Element.intersectTest (elements/parent.py:30-42; geom/shape.py:25-59; primitives.py:38-57)
  * t_out[s*ld_t + i] = distance to surface s of the program, inf on a miss. */
 int rtt_intersect_test_f32(const float* pos, const float* dir, int64_t ld, int64_t n,

@@ -222,6 +222,23 @@ def gen_paths(ns):
     print("paths", out["step_history"].shape)
 
 
+def gen_render(ns):
+    """Renderer.render_3d images (render/camera.py:191-257) with the camera rays that produced them."""
+    for name, (mk_elements, cam_kw) in scenes.render_cases(ns).items():
+        scene = ns.Scene()
+        for el in mk_elements():
+            scene.add_element(el)
+        scene._build_index_maps()
+        cam = ns.Camera(**cam_kw)
+        rays = cam.generate_rays()
+        with torch.no_grad():
+            img = ns.Renderer(scene).render_3d(cam)
+            t_matrix = torch.cat([el.intersectTest(rays) for el in scene.elements], dim=1)
+        np.savez_compressed(os.path.join(OUT, f"render_{name}.npz"), image=npy(img), t_matrix=npy(t_matrix),
+                            **rays_arrays(rays, "in_"))
+        print("render", name, tuple(img.shape), float((img != 1.0).any(-1).float().mean()))
+
+
 def gen_physics(ns):
     """Functors called directly.  RefractFresnel consumes torch.rand_like(R) ([N,1]) once per call; the same
     values are recorded by re-seeding."""
@@ -250,6 +267,8 @@ def main():
         return gen_physics(ns)
     if sys.argv[1:] == ["paths"]:
         return gen_paths(ns)
+    if sys.argv[1:] == ["render"]:
+        return gen_render(ns)
     if sys.argv[1:2] == ["seq"]:
         return gen_sequential(ns, only=sys.argv[2:])
     gen_primitives(ns)
@@ -261,6 +280,7 @@ def main():
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)
+    gen_render(ns)
 
 
 if __name__ == "__main__":

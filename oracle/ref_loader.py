@@ -92,4 +92,5 @@ def load():
     top.elements = importlib.import_module("RayTraceTorch.elements")
     top.scene = importlib.import_module("RayTraceTorch.scene")
     top.optim = importlib.import_module("RayTraceTorch.optim")
+    top.render = importlib.import_module("RayTraceTorch.render.camera")
     return top

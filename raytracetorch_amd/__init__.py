@@ -1,7 +1,7 @@
 """raytracetorch_amd — MI355X (gfx950) implementation of RayTraceTorch's batched ray-propagation
 path behind the reference's Python API (rays / geom / phys / elements / scene / optim)."""
-from . import rays, geom, phys, elements, scene, optim
+from . import rays, geom, phys, elements, scene, optim, render
 from .rays import Rays
 from .scene import Scene, SequentialScene
 
-__all__ = ["rays", "geom", "phys", "elements", "scene", "optim", "Rays", "Scene", "SequentialScene"]
+__all__ = ["rays", "geom", "phys", "elements", "scene", "optim", "render", "Rays", "Scene", "SequentialScene"]

@@ -1175,10 +1175,11 @@ DI int icomp(i2 a, int k) { return k == 0 ? a.x : a.y; }
 
 template <class T>
 DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
-                typename WinOf<T>::type& win) {
+                typename WinOf<T>::type& win, uint64_t skip = 0) {
   tmin = splat<T>(kInf);
   win = typename WinOf<T>::type(0);
   for (int s = 0; s < n_surf; ++s) {
+    if ((skip >> s) & 1) continue;  // surfaces left out of the competition (wave-uniform)
     const RecF S{prog[s]};
     Frames<T> f;
     T t_raw = splat<T>(kInf), t = splat<T>(kInf);
@@ -1284,6 +1285,51 @@ __global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurf
       }
     }
     store_ray<T>(io, i, r, vec != 0, nv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Renderer.render_3d (render/camera.py:191-257, :259-318): nearest hit over the surfaces that take part,
+// the winner's global normal (Shape.forward / Surface.forward), colour = base colour of the surface times
+// 0.3 + 0.7 |n . light|, clamped to [0, 1]; pixels without a hit keep the background.
+// ------------------------------------------------------------------------------------------------
+struct ShadeIO {
+  const float* base;  // [n_surf][3] base colour per surface (device)
+  uint64_t skip;      // bit s set: surface s does not take part (aperture elements)
+  float light[3];
+  float bg[3];
+};
+
+__global__ void __launch_bounds__(kBlock) k_render(const float* __restrict__ pos, const float* __restrict__ dir, int64_t ld,
+                                                   int64_t n, const RttSurface* __restrict__ prog_, int n_surf, Ops ops,
+                                                   ShadeIO sh, float* __restrict__ rgb) {
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
+    const V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
+    float tmin;
+    int win;
+    nearest<float>(prog, n_surf, ops, p, d, tmin, win, sh.skip);
+    V3<float> c = {sh.bg[0], sh.bg[1], sh.bg[2]};
+    bool pending = win >= 0;
+    while (pending) {  // one surface per pass, its record in scalar registers
+      const int s = __builtin_amdgcn_readfirstlane(win);
+      if (win == s) {
+        const RecF S{prog[s]};
+        const Frames<float> f = to_frames<CGeneric>(S, p, d);
+        const Forward<float> fw = surface_forward<CGeneric>(S, p, d, f, tmin);
+        const float diffuse = fw.n_g.x * sh.light[0] + fw.n_g.y * sh.light[1] + fw.n_g.z * sh.light[2];
+        const float shade = 0.3f + 0.7f * fabsf(diffuse);
+        const float* b = sh.base + 3 * s;
+        c = {fminf(fmaxf(b[0] * shade, 0.0f), 1.0f), fminf(fmaxf(b[1] * shade, 0.0f), 1.0f),
+             fminf(fmaxf(b[2] * shade, 0.0f), 1.0f)};
+        pending = false;
+      }
+    }
+    rgb[3 * i] = c.x;
+    rgb[3 * i + 1] = c.y;
+    rgb[3 * i + 2] = c.z;
   }
 }
 
@@ -1811,6 +1857,21 @@ int rtt_trace_seq_history_f32(const float* pos_in, const float* dir_in, const fl
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld, 0};
   hipLaunchKernelGGL(k_trace_seq_history, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev, n_surf, se,
                      hist_pos, hist_any, hist_ld);
+  return launch_status();
+}
+
+int rtt_render_f32(const float* pos, const float* dir, int64_t ld, int64_t n, const RttSurface* prog_dev,
+                   const RttSurface* prog_host, int n_surf, const float* base_rgb, uint64_t skip_mask,
+                   const float light_dir[3], const float background[3], float* rgb, void* stream) {
+  if (!pos || !dir || !prog_dev || !base_rgb || !light_dir || !background || !rgb) return RTT_E_NULL;
+  if (n < 0 || ld < n) return RTT_E_SIZE;
+  if (misaligned(pos) || misaligned(dir) || misaligned(base_rgb) || misaligned(rgb)) return RTT_E_ALIGN;
+  int rc = check_program(prog_host, n_surf, nullptr, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (n == 0) return RTT_OK;
+  ShadeIO sh = {base_rgb, skip_mask, {light_dir[0], light_dir[1], light_dir[2]}, {background[0], background[1], background[2]}};
+  hipLaunchKernelGGL(k_render, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, pos, dir, ld, n, prog_dev, n_surf,
+                     make_ops(prog_host, n_surf), sh, rgb);
   return launch_status();
 }
 

@@ -22,6 +22,8 @@ def namespace_from_package(pkg):
     ns.Cylinder = pkg.geom.primitives.Cylinder
     ns.Cone = pkg.geom.primitives.Cone
     ns.SpotSizeLoss = pkg.optim.goals.SpotSizeLoss
+    for k in ("Camera", "OrbitCamera", "Renderer"):
+        setattr(ns, k, getattr(pkg.render, k))
     ns.Paths = pkg.rays.Paths
     ns.ElementCustom = pkg.elements.parent.ElementCustom
     ns.IdealMirror = pkg.elements.ideal.IdealMirror
@@ -263,4 +265,20 @@ def physics_cases(ns):
         "linear_posed": (lambda: ns.Linear(Cx=-0.02, Cy=-0.03, Dx=1.0, Dy=0.9,
                                            transform=ns.RayTransform(rotation=[0.1, 0.05, -0.2])), inputs),
         "linear_plain": (lambda: ns.Linear(Cx=-0.05, Cy=-0.05), inputs),
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+# renderer cases (render/camera.py): name -> (elements, camera keyword arguments)
+# ---------------------------------------------------------------------------------------------
+def render_cases(ns):
+    cam = dict(position=(30.0, 20.0, -40.0), look_at=(0.0, 0.0, 15.0), up_vector=(0.0, 1.0, 0.0), fov_deg=40.0,
+               width=96, height=64)
+    return {
+        "system5": (lambda: system5(ns), cam),
+        "box_and_lens": (lambda: [ns.ElementCustom(ns.Box(length=6.0, width=4.0, height=5.0,
+                                                          transform=T(ns, 20.0, x=6.0, rot=[0.3, -0.4, 0.1])), ns.Block(), None),
+                                  singlet(ns, inked=False), ns.CylSingletLens(c1=0.04, c2=-0.03, height=12.0, width=10.0, t=2.5,
+                                                                             ior_glass=1.7, inked=True, transform=T(ns, 10.0))],
+                         dict(cam, position=(-14.0, 10.0, -18.0), look_at=(2.0, 0.0, 10.0), fov_deg=60.0)),
     }

@@ -1,0 +1,69 @@
+"""Renderer (render/camera.py of the reference): camera rays on the CPU, the fused render kernel on the GPU
+against images produced by the unmodified reference."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from util import golden, rel_err
+
+CASES = ["system5", "box_and_lens"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_camera_rays_match_reference(ns, name):
+    g = golden("render_" + name)
+    cam = ns.Camera(**scenes.render_cases(ns)[name][1])
+    rays = cam.generate_rays()
+    assert rel_err(rays.pos.numpy(), g["in_pos"]) < 1e-6 and rel_err(rays.dir.numpy(), g["in_dir"]) < 1e-6
+
+
+def test_orbit_camera_keeps_its_distance_and_horizon(ns):
+    cam = ns.OrbitCamera(pivot=(0.0, 0.0, 10.0), position=(0.0, 5.0, -30.0), look_at=(0.0, 0.0, 10.0),
+                         up_vector=(0.0, 1.0, 0.0), fov_deg=40.0, width=8, height=6)
+    r0 = float(torch.norm(cam.origin - cam.pivot))
+    cam.orbit(0.3, -0.2)
+    assert abs(float(torch.norm(cam.origin - cam.pivot)) - r0) < 1e-4
+    assert abs(float(cam.right[1])) < 1e-6 and abs(float(torch.dot(cam.right, cam.forward))) < 1e-6
+    cam.zoom(2.0)
+    assert abs(float(torch.norm(cam.origin - cam.pivot)) - 0.8 * r0) < 1e-4
+    cam.pan(1.0, 0.5)
+    cam.roll(0.1)
+    assert cam.generate_rays().pos.shape == (48, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_render_matches_reference(ns, name):
+    g = golden("render_" + name)
+    mk_elements, cam_kw = scenes.render_cases(ns)[name]
+    scene = ns.Scene()
+    for el in mk_elements():
+        scene.add_element(el)
+    cam = ns.Camera(device="cuda:0", **cam_kw)
+    img = ns.Renderer(scene).render_3d(cam)
+    assert tuple(img.shape) == g["image"].shape and not img.is_cuda
+    got, ref = img.numpy().reshape(-1, 3), g["image"].reshape(-1, 3)
+    # pixels whose two nearest surfaces are closer than float32 noise (silhouettes, cemented edges) may pick
+    # either surface; everywhere else the colours agree
+    srt = np.sort(np.where(np.isfinite(g["t_matrix"]), g["t_matrix"], np.inf), axis=1)
+    with np.errstate(invalid="ignore"):
+        tie = np.isfinite(srt[:, 1]) & (np.abs(srt[:, 1] - srt[:, 0]) <= 1e-4 * np.abs(srt[:, 0]))
+    assert tie.mean() < 0.02
+    lit = (ref != 1.0).any(1)
+    assert lit.mean() > 0.05
+    bad = (np.abs(got - ref).max(1) > 2e-5) & ~tie
+    assert bad.sum() == 0, f"{bad.sum()} pixels differ (worst {np.abs(got - ref)[~tie].max():.3g})"
+
+
+@pytest.mark.gpu
+def test_scan_profile(ns):
+    lens = scenes.singlet(ns)
+    scene = ns.Scene()
+    scene.add_element(lens)
+    lens.to("cuda:0")
+    prof = ns.Renderer(scene).scan_profile(lens, axis="y", num_points=101)
+    faces = {p["surf_idx"]: p for p in prof}
+    assert set(faces) == {0, 1}    # an axial scan sees the two faces, never the edge cylinder
+    mid = np.argmin(np.abs(faces[0]["h"]))
+    assert abs(faces[0]["z"][mid] + 1.5) < 1e-4 and abs(faces[1]["z"][mid] - 1.5) < 1e-4
