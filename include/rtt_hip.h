@@ -241,6 +241,14 @@ typedef struct RttSource {
 int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t ld, float* inten, int8_t* id,
                           float* wavelength, int64_t n, void* stream);
 
+/* ---- per-id spot sizes: Sensor.getSpotSizeParallel_xy (elements/sensor.py:87-176) ---------------
+ * Hits are given densely (x, y, w, id per ray; mask != 0 marks a recorded hit, NULL = all).  Group g = id + 128.
+ * pass 0: out[3g + (0,1,2)] += sum w, sum w x, sum w y.
+ * pass 1: out[3g + (0,1)] += sum w |x - centers[2g]|^norm_ord, sum w |y - centers[2g+1]|^norm_ord.
+ * out is [256][3] float64 in device memory (zeroed by the caller before each pass), centers [256][2] float64. */
+int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const uint8_t* mask, const int8_t* id,
+                        int64_t n, int pass, const double* centers, double norm_ord, double* out, void* stream);
+
 /* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1, 2 or 4);
  * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride);
  * key 2: 1 stages the surface program in LDS, 0 (default) reads it with scalar loads.

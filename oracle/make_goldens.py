@@ -239,6 +239,26 @@ def gen_render(ns):
         print("render", name, tuple(img.shape), float((img != 1.0).any(-1).float().mean()))
 
 
+def gen_sensor_groups(ns):
+    """Sensor.getSpotSizeParallel_xy (elements/sensor.py:87-176) on hits of two bundles with different ids."""
+    torch.manual_seed(0)
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    scene = ns.SequentialScene([lens, sensor])
+    a = scenes.disk_bundle(ns, ray_id=0).sample(3000)
+    b = scenes.disk_bundle(ns, radius=2.0, x=1.0, y=-0.5, rot=[0.01, 0.02, 0.0], ray_id=3).sample(2000)
+    out = {}
+    out.update(rays_arrays(a, "a_")); out.update(rays_arrays(b, "b_"))
+    with torch.no_grad():
+        scene.simulate(a); scene.simulate(b)
+        tgt = torch.tensor([[0.1, -0.2], [0.0, 0.0], [0.3, 0.3]])
+        for tag, kw in (("centroid_p2", {}), ("centroid_p3", dict(norm_ord=3)), ("target_p2", dict(target_xy=tgt))):
+            spot, wsum = sensor.getSpotSizeParallel_xy([3, 0, 7], **kw)
+            out[f"{tag}_spot"], out[f"{tag}_wsum"] = npy(spot), npy(wsum)
+    out["target"] = npy(tgt)
+    np.savez_compressed(os.path.join(OUT, "sensor_groups.npz"), **out)
+    print("sensor_groups", out["centroid_p2_spot"], out["centroid_p2_wsum"])
+
+
 def gen_physics(ns):
     """Functors called directly.  RefractFresnel consumes torch.rand_like(R) ([N,1]) once per call; the same
     values are recorded by re-seeding."""
@@ -269,6 +289,8 @@ def main():
         return gen_paths(ns)
     if sys.argv[1:] == ["render"]:
         return gen_render(ns)
+    if sys.argv[1:] == ["sensor"]:
+        return gen_sensor_groups(ns)
     if sys.argv[1:2] == ["seq"]:
         return gen_sequential(ns, only=sys.argv[2:])
     gen_primitives(ns)
@@ -281,6 +303,7 @@ def main():
     gen_physics(ns)
     gen_paths(ns)
     gen_render(ns)
+    gen_sensor_groups(ns)
 
 
 if __name__ == "__main__":

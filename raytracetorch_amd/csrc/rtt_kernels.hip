@@ -1474,6 +1474,65 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sensor.getSpotSizeParallel_xy (elements/sensor.py:87-176): per-ray-id sums over recorded hits.
+// Group g = id + 128 (ids are int8).  pass 0: out[g] += (w, w x, w y); pass 1: out[g] += (w |x - cx_g|^p,
+// w |y - cy_g|^p, 0) with the centres read from `centers` [256][2].  Sums are float64: a wavefront whose hits
+// all carry one id (the usual case: a bundle has one id) reduces with shuffles, mixed wavefronts add into
+// a per-block table in LDS; each block then adds its non-zero rows to `out`.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_spot_groups(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ w, const uint8_t* __restrict__ mask,
+                                                        const int8_t* __restrict__ id, int64_t n, int pass,
+                                                        const double* __restrict__ centers, float p,
+                                                        double* __restrict__ out) {
+  __shared__ double acc[256][3];
+  for (int k = threadIdx.x; k < 256 * 3; k += kBlock) (&acc[0][0])[k] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t n_round = (n + stride - 1) / stride * stride;  // every lane of a wavefront runs every round
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += stride) {
+    const bool on = i < n && (mask == nullptr || mask[i] != 0);
+    const int g = on ? (int)id[i] + 128 : -1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (on) {
+      const float wi = w[i], xi = x[i], yi = y[i];
+      if (pass == 0) {
+        a0 = wi;
+        a1 = (double)(xi * wi);  // per-hit products in float32 like the reference's tensors
+        a2 = (double)(yi * wi);
+      } else {
+        const float dx = fabsf(xi - (float)centers[2 * g]), dy = fabsf(yi - (float)centers[2 * g + 1]);
+        a0 = (double)(wi * (p == 2.0f ? dx * dx : powf(dx, p)));
+        a1 = (double)(wi * (p == 2.0f ? dy * dy : powf(dy, p)));
+      }
+    }
+    const uint64_t active = __ballot(on);
+    if (active == 0) continue;
+    const int g0 = __shfl(g, __builtin_ctzll(active), 64);
+    if (__all(!on || g == g0)) {
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      a2 = wave_sum(a2);
+      if (lane == 0) {
+        atomicAdd(&acc[g0][0], a0);
+        atomicAdd(&acc[g0][1], a1);
+        atomicAdd(&acc[g0][2], a2);
+      }
+    } else if (on) {
+      atomicAdd(&acc[g][0], a0);
+      atomicAdd(&acc[g][1], a1);
+      atomicAdd(&acc[g][2], a2);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 256 * 3; k += kBlock) {
+    const double v = (&acc[0][0])[k];
+    if (v != 0.0) atomicAdd(&out[k], v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bundle.sample on the device (rays/bundle.py:30-171).  One lane generates the pair of rays with global
 // indices (2j, 2j+1) from one Philox4x32-10 block, applies the bundle transform and the normalisation
 // of Rays.initialize, and writes the structure-of-arrays planes: a write-only kernel.
@@ -1857,6 +1916,19 @@ int rtt_trace_seq_history_f32(const float* pos_in, const float* dir_in, const fl
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld, 0};
   hipLaunchKernelGGL(k_trace_seq_history, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev, n_surf, se,
                      hist_pos, hist_any, hist_ld);
+  return launch_status();
+}
+
+int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const uint8_t* mask, const int8_t* id, int64_t n,
+                        int pass, const double* centers, double norm_ord, double* out, void* stream) {
+  if (!x || !y || !w || !id || !out || (pass == 1 && !centers)) return RTT_E_NULL;
+  if (n < 0 || (pass != 0 && pass != 1)) return RTT_E_SIZE;
+  if (misaligned(x) || misaligned(y) || misaligned(w) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
+      (reinterpret_cast<uintptr_t>(centers) & 7u))
+    return RTT_E_ALIGN;
+  if (n == 0) return RTT_OK;
+  hipLaunchKernelGGL(k_spot_groups, dim3(grid_for_reduction(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w, mask, id, n,
+                     pass, centers, (float)norm_ord, out);
   return launch_status();
 }
 

@@ -79,27 +79,40 @@ class Sensor(Element):
             locs, inten, ids = locs[m], inten[m], ids[m]
         return locs, inten, ids
 
+    def _hit_records(self):
+        """(x, y, w, mask or None, id) device arrays of every recorded visit, dense or compacted."""
+        recs = [(hit[0], hit[1], w, mask, ids) for hit, w, mask, ids in self._dense]
+        for locs, w, ids in zip(self._locs, self._inten, self._ids):
+            recs.append((locs[:, 0].contiguous(), locs[:, 1].contiguous(), w.contiguous(), None, ids.contiguous()))
+        return recs
+
     def getSpotSizeParallel_xy(self, query_ids, target_xy=None, norm_ord=2):
-        """Per-id weighted moments sum_i w |x - c|^p / (2 sum w) (elements/sensor.py:87-176).
-        Returns (spot [K], intensity_sum [K]) in the order of `query_ids`."""
-        xyz, w, ids = self.getHitsTensors()
-        q = torch.as_tensor(query_ids, device=ids.device, dtype=torch.int32)
-        keep = torch.isin(ids, q)
-        xy, w, ids = xyz[keep][:, :2], w[keep], ids[keep]
-        q_sorted, order = torch.sort(q)
-        g = torch.searchsorted(q_sorted, ids.to(torch.int32))
-        k = q.shape[0]
-        wsum = torch.zeros(k, device=ids.device, dtype=w.dtype).scatter_add(0, g, w)
+        """Per-id weighted moments sum_i w |x - c|^p / (2 sum w) (elements/sensor.py:87-176), as two segmented
+        reductions over the recorded hits (``rtt_spot_groups_f32``; nothing is compacted, sorted or gathered).
+        Returns (spot [K] in the order of `query_ids`, intensity_sum [K] in the order of the *sorted* ids, as
+        the reference does).  The result carries no autograd graph."""
+        from .. import kernels as K
+        recs = self._hit_records()
+        if not recs:
+            raise RuntimeError("no hits recorded")   # the reference fails in torch.cat of empty lists
+        dev = recs[0][2].device
+        q = torch.as_tensor(query_ids, device=dev).to(torch.int64).reshape(-1)
+        inside = (q >= -128) & (q <= 127)
+        g = torch.where(inside, q + 128, torch.zeros_like(q))
+        sums = torch.zeros((256, 3), device=dev, dtype=torch.float64)
+        for x, y, w, mask, ids in recs:
+            K.spot_groups(x, y, w, mask, ids, 0, None, float(norm_ord), sums)
+        pick = lambda t: torch.where(inside[:, None], t[g], torch.zeros_like(t[g]))
+        s0 = pick(sums)
+        wsum = s0[:, 0]
         denom = torch.where(wsum == 0, torch.ones_like(wsum), wsum)
-        g2 = g.unsqueeze(1).expand(-1, 2)
-        if target_xy is None:
-            cen = torch.zeros(k, 2, device=ids.device, dtype=xy.dtype).scatter_add(0, g2, xy * w[:, None])
-            cen = cen / denom[:, None]
-        else:
-            cen = target_xy[order]
-        mom = torch.zeros(k, 2, device=ids.device, dtype=xy.dtype).scatter_add(
-            0, g2, w[:, None] * (xy - cen[g]).abs() ** norm_ord)
-        spot_sorted = mom.sum(dim=1) / (2 * denom)
-        spot = torch.empty_like(spot_sorted)
-        spot[order] = spot_sorted
-        return spot, wsum
+        cen = s0[:, 1:3] / denom[:, None] if target_xy is None else torch.as_tensor(target_xy, device=dev).to(torch.float64)
+        centers = torch.zeros((256, 2), device=dev, dtype=torch.float64)
+        centers[g[inside]] = cen[inside]
+        mom = torch.zeros((256, 3), device=dev, dtype=torch.float64)
+        for x, y, w, mask, ids in recs:
+            K.spot_groups(x, y, w, mask, ids, 1, centers, float(norm_ord), mom)
+        m1 = pick(mom)
+        spot = (m1[:, 0] + m1[:, 1]) / (2 * denom)
+        order = torch.sort(q).indices
+        return spot.to(torch.float32), wsum[order].to(torch.float32)

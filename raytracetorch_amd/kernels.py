@@ -226,3 +226,26 @@ def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: in
                                                  N.ptr(ids), N.ptr(wl), n, N.stream_handle(device))
         N.check(code, "rtt_sample_bundle_f32")
     return Rays.from_planes(pos, dir_, inten, ids, wl)
+
+
+def spot_groups(x, y, w, mask, ids, pass_id: int, centers, norm_ord: float, out: torch.Tensor):
+    """Accumulate per-id sums of recorded hits into `out` ([256, 3] float64 on the device)."""
+    N.require_device(x, y, w, ids, out)
+    n = x.numel()
+    if out.dtype != torch.float64 or tuple(out.shape) != (256, 3) or not out.is_contiguous():
+        raise ValueError("`out` must be a contiguous [256, 3] float64 tensor")
+    if ids.dtype != torch.int8 or ids.numel() != n or not ids.is_contiguous():
+        raise ValueError("ids must be a contiguous int8 tensor with one entry per hit slot")
+    for t in (x, y, w):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError("x, y, w must be contiguous float32 tensors of equal length")
+    if mask is not None and (mask.dtype != torch.uint8 or mask.numel() != n or not mask.is_contiguous()):
+        raise ValueError("mask must be a contiguous uint8 tensor of the same length")
+    if centers is not None and (centers.dtype != torch.float64 or tuple(centers.shape) != (256, 2) or not centers.is_contiguous()):
+        raise ValueError("centers must be a contiguous [256, 2] float64 tensor")
+    if n:
+        with torch.cuda.device(x.device):
+            code = N.lib().rtt_spot_groups_f32(N.ptr(x), N.ptr(y), N.ptr(w), N.ptr(mask), N.ptr(ids), n, int(pass_id),
+                                               N.ptr(centers), float(norm_ord), N.ptr(out), N.stream_handle(x.device))
+        N.check(code, "rtt_spot_groups_f32")
+    return out

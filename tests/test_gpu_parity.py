@@ -252,3 +252,26 @@ def _state_before(prog, s, p0, d0, I0):
         return p0, d0
     o = O.trace_sequential(prog[:s], p0, d0, I0)
     return o["pos"].numpy(), o["dir"].numpy()
+
+
+def test_sensor_spot_sizes_per_id(ns):
+    """Sensor.getSpotSizeParallel_xy (elements/sensor.py:87-176) through the segmented-reduction kernel, for
+    dense trace records and for the per-hit lists of direct Sensor.forward calls."""
+    g = golden("sensor_groups")
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    scene = ns.SequentialScene([lens, sensor])
+    for tag in ("a_", "b_"):
+        scene.simulate(rays_from_golden(ns, g, prefix=tag, device=DEV))
+    tgt = torch.from_numpy(g["target"]).to(DEV)
+    for tag, kw in (("centroid_p2", {}), ("centroid_p3", dict(norm_ord=3)), ("target_p2", dict(target_xy=tgt))):
+        spot, wsum = sensor.getSpotSizeParallel_xy([3, 0, 7], **kw)
+        assert np.array_equal(cpu(wsum), g[f"{tag}_wsum"]), tag
+        assert rel_err(cpu(spot), g[f"{tag}_spot"]) < 1e-4, tag     # float32 scatter_add sums on the reference side
+    # the same hits as compacted lists (what Sensor.forward on a ray subset records)
+    _ = sensor.hitLocs
+    assert not sensor._dense and len(sensor._locs) == 2
+    spot2, wsum2 = sensor.getSpotSizeParallel_xy([3, 0, 7])
+    assert np.array_equal(cpu(wsum2), g["centroid_p2_wsum"]) and rel_err(cpu(spot2), g["centroid_p2_spot"]) < 1e-4
+    sensor.reset()
+    with pytest.raises(RuntimeError):
+        sensor.getSpotSizeParallel_xy([0])
