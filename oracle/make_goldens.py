@@ -259,6 +259,25 @@ def gen_sensor_groups(ns):
     print("sensor_groups", out["centroid_p2_spot"], out["centroid_p2_wsum"])
 
 
+def gen_project(ref):
+    """load_scene (project.py:96-179) of tests/golden/system5.rtt by the reference: what it builds (class names,
+    parameter values), the rays it samples under seed 0, and the first bounce."""
+    torch.manual_seed(0)
+    scene = ref.project.load_scene(os.path.join(OUT, "system5.rtt"), device="cpu")
+    out = rays_arrays(scene.rays, "in_")
+    out["classes"] = np.array([type(el).__name__ for el in scene.elements] + [type(b).__name__ for b in scene.bundles])
+    out["names"] = np.array(scene.element_names + scene.bundle_names)
+    for k, v in scene.state_dict().items():
+        if k.startswith(("elements.", "bundles.")) and v.dtype.is_floating_point:
+            out["param/" + k] = npy(v)
+    out["nbounces"] = np.int32(scene.Nbounces)
+    with torch.no_grad():
+        scene.step()
+    out.update(rays_arrays(scene.rays, "step1_"))
+    np.savez_compressed(os.path.join(OUT, "project_system5.npz"), **out)
+    print("project", list(out["classes"]), len(out["in_pos"]))
+
+
 def gen_physics(ns):
     """Functors called directly.  RefractFresnel consumes torch.rand_like(R) ([N,1]) once per call; the same
     values are recorded by re-seeding."""
@@ -291,6 +310,8 @@ def main():
         return gen_render(ns)
     if sys.argv[1:] == ["sensor"]:
         return gen_sensor_groups(ns)
+    if sys.argv[1:] == ["project"]:
+        return gen_project(ref)
     if sys.argv[1:2] == ["seq"]:
         return gen_sequential(ns, only=sys.argv[2:])
     gen_primitives(ns)
@@ -304,6 +325,7 @@ def main():
     gen_paths(ns)
     gen_render(ns)
     gen_sensor_groups(ns)
+    gen_project(ref)
 
 
 if __name__ == "__main__":

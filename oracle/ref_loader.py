@@ -93,4 +93,5 @@ def load():
     top.scene = importlib.import_module("RayTraceTorch.scene")
     top.optim = importlib.import_module("RayTraceTorch.optim")
     top.render = importlib.import_module("RayTraceTorch.render.camera")
+    top.project = importlib.import_module("RayTraceTorch.project")
     return top

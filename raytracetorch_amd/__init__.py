@@ -3,5 +3,7 @@ path behind the reference's Python API (rays / geom / phys / elements / scene / 
 from . import rays, geom, phys, elements, scene, optim, render
 from .rays import Rays
 from .scene import Scene, SequentialScene
+from .project import load_scene, load_project, save_project
 
-__all__ = ["rays", "geom", "phys", "elements", "scene", "optim", "render", "Rays", "Scene", "SequentialScene"]
+__all__ = ["rays", "geom", "phys", "elements", "scene", "optim", "render", "Rays", "Scene", "SequentialScene", "load_scene", "load_project",
+           "save_project"]
