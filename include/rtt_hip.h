@@ -251,7 +251,9 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
 
 /* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1, 2 or 4);
  * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride);
- * key 2: 1 stages the surface program in LDS, 0 (default) reads it with scalar loads.
+ * key 2: 1 stages the surface program in LDS, 0 (default) reads it with scalar loads;
+ * key 3: 0 makes the nearest-hit kernels test every surface for every ray, 1 (default) lets them skip elements
+ * whose bounding sphere lies beyond the nearest hit found so far (same results).
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <type_traits>
 
 #include "rtt_hip.h"
@@ -1172,47 +1173,144 @@ template <class T> struct WinOf { using type = int; };
 template <> struct WinOf<f2> { using type = i2; };
 DI int icomp(int a, int) { return a; }
 DI int icomp(i2 a, int k) { return k == 0 ? a.x : a.y; }
+DI bool isel_lt(int s, int win) { return s < win; }
+DI b2 isel_lt(int s, i2 win) { return __builtin_convertvector(i2(s) < win, b2); }
+DI bool eq_(float a, float b) { return a == b; }
+DI b2 eq_(f2 a, f2 b) { return __builtin_convertvector(a == b, b2); }
+
+// Element table for culling in the nearest-hit search: element e owns the records first[e] .. first[e] +
+// count[e] - 1 and lies inside the sphere (c[e], R[e]) in global coordinates; R < 0 marks an element without a
+// usable bound (unbounded or inverted surfaces).  Built on the host from the surface records; n = 0 disables
+// culling (more than kMaxCull elements, or no host copy of the program).
+constexpr int kMaxCull = 32;
+struct Cull {
+  int n;
+  uint8_t first[kMaxCull], count[kMaxCull];
+  float c[kMaxCull][3], R[kMaxCull];
+};
+
+// torch.min over the row of distances, independent of the order in which the surfaces are visited: the
+// smallest t wins, the lower surface index on equal t, and a NaN beats every number (the first NaN in program
+// order wins), exactly as torch.min(t_matrix, dim=1) returns it.
+template <class T>
+DI void offer(T t, int s, T& tmin, typename WinOf<T>::type& win) {
+  const auto lower = isel_lt(s, win);
+  const auto t_nan = isnan_(t), m_nan = isnan_(tmin);
+  const auto take = or_(and_(t_nan, or_(not_(m_nan), lower)),
+                        and_(not_(or_(t_nan, m_nan)), or_(lt(t, tmin), and_(eq_(t, tmin), lower))));
+  tmin = sel(take, t, tmin);
+  win = isel(take, s, win);
+}
 
 template <class T>
-DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
-                typename WinOf<T>::type& win, uint64_t skip = 0) {
-  tmin = splat<T>(kInf);
-  win = typename WinOf<T>::type(0);
-  for (int s = 0; s < n_surf; ++s) {
-    if ((skip >> s) & 1) continue;  // surfaces left out of the competition (wave-uniform)
-    const RecF S{prog[s]};
-    Frames<T> f;
-    T t_raw = splat<T>(kInf), t = splat<T>(kInf);
+DI T test_one(const RttSurface* __restrict__ prog, const Ops& ops, int s, V3<T> p, V3<T> d) {
+  const RecF S{prog[s]};
+  Frames<T> f;
+  T t_raw = splat<T>(kInf), t = splat<T>(kInf);
 #define RTT_CALL(CFG)                                          \
   {                                                            \
     const auto valid = test_surface<CFG>(S, p, d, f, t_raw);   \
     t = masked_t<CFG>(S, t_raw, valid);                        \
   }
-    RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+  RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
-    const auto take = and_(not_(isnan_(tmin)), or_(isnan_(t), lt(t, tmin)));
-    tmin = sel(take, t, tmin);
-    win = isel(take, s, win);
+  return t;
+}
+
+// Lower bound of the distance at which the ray can meet anything inside the sphere (c, R): -inf when the origin
+// is inside or the direction is degenerate, +inf when the ray misses the sphere, otherwise the entry distance
+// less a margin that covers the rounding of this estimate.  Any surface of the element has t >= this bound.
+template <class T>
+DI T sphere_entry(V3<T> p, V3<T> d, float cx, float cy, float cz, float R) {
+  const V3<T> oc = {cx - p.x, cy - p.y, cz - p.z};
+  const T a = dot3(d, d), b = dot3(oc, d), c = dot3(oc, oc) - R * R;
+  const T disc = b * b - a * c;
+  const auto misses = or_(lt(disc, splat<T>(0.0f)), le(b, splat<T>(0.0f)));
+  const T entry = (b - sqrt_(max_(disc, splat<T>(0.0f)))) * rcp_(a);
+  T lb = sel(misses, splat<T>(kInf), entry * 0.9999f - 1e-3f);
+  // origin inside the sphere, a direction that is not a direction (dead rays carry d = 0), or NaN input
+  const auto open = or_(not_(gt(c, splat<T>(0.0f))), not_(gt(a, splat<T>(1e-12f))));
+  return sel(or_(open, isnan_(lb)), splat<T>(-kInf), lb);
+}
+
+DI float lane_min2(float v) { return v; }
+DI float lane_min2(f2 v) { return v.x < v.y ? v.x : v.y; }
+
+template <class T>
+DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
+                typename WinOf<T>::type& win, const Cull& cull, uint64_t skip = 0) {
+  tmin = splat<T>(kInf);
+  win = typename WinOf<T>::type(0x7fffffff);
+  if (cull.n == 0) {
+    for (int s = 0; s < n_surf; ++s) {
+      if ((skip >> s) & 1) continue;  // surfaces left out of the competition (wave-uniform)
+      offer(test_one<T>(prog, ops, s, p, d), s, tmin, win);
+    }
+  } else {
+    // Front-to-back over the elements, in the order the wavefront's first ray meets their bounding spheres
+    // (a heuristic: the rays of a wavefront are neighbours).  An element is skipped when, for every ray of the
+    // wavefront, its sphere lies beyond the nearest hit found so far; since any t of the element is at least
+    // the entry distance, a skipped element can neither win nor tie.  Every lane of the wavefront is active
+    // here (the kernels clamp instead of masking), so lane e can hold the sort key of element e.
+    const int lane = threadIdx.x & 63;
+    float key = 0.0f;
+    for (int e = 0; e < cull.n; ++e) {
+      float k = -kInf;
+      if (cull.R[e] >= 0.0f) {
+        const float mine = lane_min2(sphere_entry(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]));
+        k = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mine)));
+      }
+      key = lane == e ? k : key;
+    }
+    int rank = 0;  // lane e: number of elements visited before element e
+    for (int e = 0; e < cull.n; ++e) {
+      const float ke = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key), e));
+      rank += (ke < key || (ke == key && e < lane)) ? 1 : 0;
+    }
+    uint64_t todo = cull.n >= 64 ? ~0ull : ((1ull << cull.n) - 1);  // elements not visited yet
+    for (int k = 0; k < cull.n; ++k) {
+      // the element of rank k; whatever the keys are, every element is visited exactly once
+      const uint64_t pick = __ballot(rank == k) & todo;
+      const int e = __builtin_ctzll(pick ? pick : todo);
+      todo &= ~(1ull << e);
+      if (cull.R[e] >= 0.0f) {
+        const T lb = sphere_entry(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
+        if (__all(all_(gt(lb, tmin)))) continue;
+      }
+      const int s0 = cull.first[e], s1 = s0 + cull.count[e];
+      for (int s = s0; s < s1; ++s) {
+        if ((skip >> s) & 1) continue;
+        offer(test_one<T>(prog, ops, s, p, d), s, tmin, win);
+      }
+    }
   }
   win = isel(not_(lt(tmin, splat<T>(kInf))), -1, win);
 }
 
+// In the three nearest-hit kernels every lane of a wavefront stays in the loop for the same number of rounds:
+// a lane past the end of the bundle works on a copy of the first ray and stores nothing (`live` false), so the
+// wavefront-wide decisions of nearest() see all 64 lanes.
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ pos, const float* __restrict__ dir,
                                                      int64_t ld, int64_t n, const RttSurface* __restrict__ prog_,
-                                                     int n_surf, Ops ops, int32_t* __restrict__ winner,
+                                                     int n_surf, Ops ops, Cull cull, int32_t* __restrict__ winner,
                                                      float* __restrict__ tmin_out, int vec) {
   constexpr int N = LaneOf<T>::N;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
-  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < n; i += stride) {
+  const int64_t rounds = (n + stride - 1) / stride;
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t want = r * stride + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N;
+    const bool live = want < n;
+    const int64_t i = live ? want : 0;
     const int nv = (n - i) >= N ? N : 1;
     T* tag = nullptr;
     V3<T> p = {ld_(pos, i, vec != 0, nv, tag), ld_(pos + ld, i, vec != 0, nv, tag), ld_(pos + 2 * ld, i, vec != 0, nv, tag)};
     V3<T> d = {ld_(dir, i, vec != 0, nv, tag), ld_(dir + ld, i, vec != 0, nv, tag), ld_(dir + 2 * ld, i, vec != 0, nv, tag)};
     T tmin;
     typename WinOf<T>::type win;
-    nearest<T>(prog, n_surf, ops, p, d, tmin, win);
+    nearest<T>(prog, n_surf, ops, p, d, tmin, win, cull);
+    if (!live) continue;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       if (k >= nv) break;
@@ -1264,16 +1362,22 @@ DI void ray_set(Ray<f2>& r, int k, const Ray<float>& v) {
 
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                         Ops ops, int32_t* __restrict__ winner, SensorIO se, int vec) {
+                                                         Ops ops, Cull cull, int32_t* __restrict__ winner, SensorIO se,
+                                                         int vec) {
   constexpr int N = LaneOf<T>::N;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
-  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N; i < io.n; i += stride) {
+  const int64_t rounds = (io.n + stride - 1) / stride;
+  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    const int64_t want = rnd * stride + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N;
+    const bool live = want < io.n;
+    const int64_t i = live ? want : 0;
     const int nv = (io.n - i) >= N ? N : 1;
     Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
     T tmin;
     typename WinOf<T>::type win;
-    nearest<T>(prog, n_surf, ops, r.p, r.d, tmin, win);
+    nearest<T>(prog, n_surf, ops, r.p, r.d, tmin, win, cull);
+    if (!live) continue;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       if (k < nv) {
@@ -1302,15 +1406,20 @@ struct ShadeIO {
 
 __global__ void __launch_bounds__(kBlock) k_render(const float* __restrict__ pos, const float* __restrict__ dir, int64_t ld,
                                                    int64_t n, const RttSurface* __restrict__ prog_, int n_surf, Ops ops,
-                                                   ShadeIO sh, float* __restrict__ rgb) {
+                                                   Cull cull, ShadeIO sh, float* __restrict__ rgb) {
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+  const int64_t rounds = (n + stride - 1) / stride;
+  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    const int64_t want = rnd * stride + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = want < n;
+    const int64_t i = live ? want : 0;
     const V3<float> p = {pos[i], pos[ld + i], pos[2 * ld + i]};
     const V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
     float tmin;
     int win;
-    nearest<float>(prog, n_surf, ops, p, d, tmin, win, sh.skip);
+    nearest<float>(prog, n_surf, ops, p, d, tmin, win, cull, sh.skip);
+    if (!live) continue;
     V3<float> c = {sh.bg[0], sh.bg[1], sh.bg[2]};
     bool pending = win >= 0;
     while (pending) {  // one surface per pass, its record in scalar registers
@@ -1616,6 +1725,7 @@ int g_program_in_lds = 0;  // 1: stage the surface program in LDS instead of rea
 // loads, which overlaps HBM latency with the arithmetic of the resident waves (measured on the 64 Mi
 // singlet trace: 0.83 ms with a 2048-block grid-stride cap, 0.77 ms uncapped).
 int g_max_blocks = 1 << 20;
+int g_cull = 1;  // 0: the nearest-hit kernels test every surface for every ray (no bounding-sphere culling)
 
 int grid_for(int64_t n, int rays_per_lane = 1) {
   const int64_t tile = (int64_t)kBlock * rays_per_lane;
@@ -1661,6 +1771,132 @@ Ops make_ops(const RttSurface* host, int n_surf) {
   if (host)
     for (int s = 0; s < n_surf; ++s) ops.w[s >> 2] |= (uint32_t)classify(host[s]) << ((s & 3) * 8);
   return ops;
+}
+
+// ---- bounding spheres for the culling nearest-hit search -----------------------------------------------
+// sagitta of a conic at height r, limited to the reach of the half-surface bound |z c| < 1
+float conic_sag(float c, float c1k, float r) {
+  if (c == 0.0f) return 0.0f;
+  const float term = 1.0f - c * c1k * r * r;
+  const float z = c * r * r / (1.0f + sqrtf(term > 0.0f ? term : 0.0f));
+  const float reach = 1.000001f / fabsf(c);
+  return fabsf(z) < reach ? z : (z < 0.0f ? -reach : reach);
+}
+
+bool is_identity(const float* R) {
+  return R[0] == 1.0f && R[4] == 1.0f && R[8] == 1.0f && R[1] == 0.0f && R[2] == 0.0f && R[3] == 0.0f && R[5] == 0.0f &&
+         R[6] == 0.0f && R[7] == 0.0f;
+}
+
+// Sphere around everything a ray can hit on the records [first, first + count) of one element, in global
+// coordinates; returns false when the element has no finite extent this routine can derive (unbounded or
+// inverted surfaces, general polyhedra, surfaces posed off the element axis).
+bool element_sphere(const RttSurface* rec, int count, float c_out[3], float* R_out) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};  // box in the local frame
+  auto grow = [&](float x0, float x1, float y0, float y1, float z0, float z1) {
+    const float a[3] = {fminf(x0, x1), fminf(y0, y1), fminf(z0, z1)}, b[3] = {fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1)};
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fminf(lo[k], a[k]);
+      hi[k] = fmaxf(hi[k], b[k]);
+    }
+  };
+  const RttSurface& S0 = rec[0];
+  const bool shaped = (S0.flags & RTT_F_HAS_SHAPE) != 0;
+  const float* R = shaped ? S0.Rs : S0.Rj;  // local frame of the box -> global: g = t + R local
+  const float* t = shaped ? S0.ts : S0.tj;
+  if (!shaped && count != 1) return false;
+  for (int q = 0; q < count; ++q) {
+    const RttSurface& S = rec[q];
+    if (S.flags & RTT_F_INVERT) return false;
+    if (shaped) {
+      if (!(S.flags & RTT_F_HAS_SHAPE)) return false;
+      for (int k = 0; k < 9; ++k)
+        if (S.Rs[k] != S0.Rs[k]) return false;
+      for (int k = 0; k < 3; ++k)
+        if (S.ts[k] != S0.ts[k]) return false;
+      const float c = S.geom[0], c1k = S.geom[2];
+      switch (S.shape_kind) {
+        case RTT_SHP_SPHERIC_FACE: {
+          if (S.surf_kind != RTT_SURF_QUADRIC || !is_identity(S.Rj) || S.tj[0] != 0.0f || S.tj[1] != 0.0f) return false;
+          const float r = sqrtf(S.shp[0]);
+          grow(-r, r, -r, r, S.tj[2], S.tj[2] + conic_sag(c, c1k, r));
+          break;
+        }
+        case RTT_SHP_SPHERIC_EDGE: {
+          if (S.surf_kind != RTT_SURF_CYLINDER || !is_identity(S.Rj) || S.tj[0] != 0.0f || S.tj[1] != 0.0f) return false;
+          const float r = S.geom[0];
+          grow(-r, r, -r, r, S.shp[0], S.shp[1]);
+          break;
+        }
+        case RTT_SHP_CYL_FACE: {
+          if (S.surf_kind != RTT_SURF_QUADRIC_ZY || !is_identity(S.Rj) || S.tj[0] != 0.0f || S.tj[1] != 0.0f) return false;
+          const float ym = fmaxf(fabsf(S.shp[2]), fabsf(S.shp[3]));
+          grow(S.shp[1], S.shp[0], S.shp[3], S.shp[2], S.tj[2], S.tj[2] + conic_sag(c, c1k, ym));
+          break;
+        }
+        case RTT_SHP_CYL_EDGE: {
+          // side planes: inside the aperture box and between the two sag curves, whose parameters the record carries
+          const float ym = fmaxf(fabsf(S.shp[2]), fabsf(S.shp[3]));
+          const float z0 = S.shp[5], z1 = S.shp[7];
+          grow(S.shp[1], S.shp[0], S.shp[3], S.shp[2], fminf(z0, z0 + conic_sag(S.shp[4], S.shp[4], ym)),
+               fmaxf(z1, z1 + conic_sag(S.shp[6], S.shp[6], ym)));
+          break;
+        }
+        default:
+          return false;
+      }
+    } else {
+      const float c = S.geom[0], c1k = S.geom[2];
+      if (S.surf_kind == RTT_SURF_PLANE && S.bound_kind == RTT_BND_DISK) {
+        const float r = sqrtf(S.bnd[0]);
+        grow(-r, r, -r, r, 0.0f, 0.0f);
+      } else if (S.surf_kind == RTT_SURF_PLANE && S.bound_kind == RTT_BND_RECT) {
+        grow(-S.bnd[0], S.bnd[0], -S.bnd[1], S.bnd[1], 0.0f, 0.0f);
+      } else if (S.surf_kind == RTT_SURF_PLANE && S.bound_kind == RTT_BND_ELLIPSE) {
+        const float r = fmaxf(fabsf(S.bnd[2]), fabsf(S.bnd[3]));
+        grow(-r, r, -r, r, 0.0f, 0.0f);
+      } else if (S.surf_kind == RTT_SURF_QUADRIC && S.bound_kind == RTT_BND_HALF_DISK) {
+        const float r = sqrtf(S.bnd[0]);
+        grow(-r, r, -r, r, 0.0f, conic_sag(c, c1k, r));
+      } else {
+        return false;
+      }
+    }
+  }
+  float cl[3], half2 = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    if (!(lo[k] <= hi[k]) || !std::isfinite(lo[k]) || !std::isfinite(hi[k])) return false;
+    cl[k] = 0.5f * (lo[k] + hi[k]);
+    const float h = 0.5f * (hi[k] - lo[k]);
+    half2 += h * h;
+  }
+  for (int i = 0; i < 3; ++i) c_out[i] = t[i] + R[3 * i] * cl[0] + R[3 * i + 1] * cl[1] + R[3 * i + 2] * cl[2];
+  const float Rb = sqrtf(half2) * 1.001f + 1e-3f;  // rounding of the records and of this estimate
+  if (!std::isfinite(Rb) || !std::isfinite(c_out[0]) || !std::isfinite(c_out[1]) || !std::isfinite(c_out[2])) return false;
+  *R_out = Rb;
+  return true;
+}
+
+// Elements are the runs of consecutive records with one element_id.
+Cull make_cull(const RttSurface* host, int n_surf) {
+  Cull cull = {};
+  if (!host || g_cull == 0) return cull;
+  int n = 0;
+  for (int s = 0; s < n_surf;) {
+    int e = s + 1;
+    while (e < n_surf && host[e].element_id == host[s].element_id) ++e;
+    if (n == kMaxCull) {
+      cull.n = 0;
+      return cull;
+    }
+    cull.first[n] = (uint8_t)s;
+    cull.count[n] = (uint8_t)(e - s);
+    if (!element_sphere(host + s, e - s, cull.c[n], &cull.R[n])) cull.R[n] = -1.0f;
+    ++n;
+    s = e;
+  }
+  cull.n = n;
+  return cull;
 }
 
 int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_slots, bool with_siblings = true) {
@@ -1804,7 +2040,7 @@ int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, 
   if (n == 0) return RTT_OK;
   const int vec = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(dir)) & 7u) == 0;
   hipLaunchKernelGGL(k_ray_cast<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, pos, dir, ld, n,
-                     prog_dev, n_surf, make_ops(prog_host, n_surf), winner, tmin, vec);
+                     prog_dev, n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), winner, tmin, vec);
   return launch_status();
 }
 
@@ -1831,7 +2067,7 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
   hipLaunchKernelGGL(k_step_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
-                     n_surf, make_ops(prog_host, n_surf), winner, se, vec);
+                     n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), winner, se, vec);
   return launch_status();
 }
 
@@ -1943,7 +2179,7 @@ int rtt_render_f32(const float* pos, const float* dir, int64_t ld, int64_t n, co
   if (n == 0) return RTT_OK;
   ShadeIO sh = {base_rgb, skip_mask, {light_dir[0], light_dir[1], light_dir[2]}, {background[0], background[1], background[2]}};
   hipLaunchKernelGGL(k_render, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, pos, dir, ld, n, prog_dev, n_surf,
-                     make_ops(prog_host, n_surf), sh, rgb);
+                     make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), sh, rgb);
   return launch_status();
 }
 
@@ -1986,6 +2222,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 1 && value >= 1 && value <= (1 << 20)) {
     g_max_blocks = value;
+    return RTT_OK;
+  }
+  if (key == 3 && (value == 0 || value == 1)) {
+    g_cull = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;
