@@ -1217,24 +1217,36 @@ DI T test_one(const RttSurface* __restrict__ prog, const Ops& ops, int s, V3<T> 
   return t;
 }
 
-// Lower bound of the distance at which the ray can meet anything inside the sphere (c, R): -inf when the origin
-// is inside or the direction is degenerate, +inf when the ray misses the sphere, otherwise the entry distance
-// less a margin that covers the rounding of this estimate.  Any surface of the element has t >= this bound.
+// Ray against the bounding sphere (c, R) of an element, without square roots or divisions.
+// With oc = c - p, a = d.d, b = oc.d, cc = oc.oc - R^2 the ray enters the sphere at (b - sqrt(b^2 - a cc)) / a.
 template <class T>
-DI T sphere_entry(V3<T> p, V3<T> d, float cx, float cy, float cz, float R) {
+struct SphereTerms {
+  T a, b, cc;
+};
+template <class T>
+DI SphereTerms<T> sphere_terms(V3<T> p, V3<T> d, float cx, float cy, float cz, float R) {
   const V3<T> oc = {cx - p.x, cy - p.y, cz - p.z};
-  const T a = dot3(d, d), b = dot3(oc, d), c = dot3(oc, oc) - R * R;
-  const T disc = b * b - a * c;
-  const auto misses = or_(lt(disc, splat<T>(0.0f)), le(b, splat<T>(0.0f)));
-  const T entry = (b - sqrt_(max_(disc, splat<T>(0.0f)))) * rcp_(a);
-  T lb = sel(misses, splat<T>(kInf), entry * 0.9999f - 1e-3f);
-  // origin inside the sphere, a direction that is not a direction (dead rays carry d = 0), or NaN input
-  const auto open = or_(not_(gt(c, splat<T>(0.0f))), not_(gt(a, splat<T>(1e-12f))));
-  return sel(or_(open, isnan_(lb)), splat<T>(-kInf), lb);
+  return {dot3(d, d), dot3(oc, d), dot3(oc, oc) - R * R};
+}
+// Sort key: b - R, a lower bound of the entry distance for a unit direction (any point q of the sphere on the
+// ray has t = b + (q - c).d >= b - R).  Only the visiting order depends on it.
+// Skip test: true when no point of the sphere can give this ray a distance <= tmin, i.e. the origin is
+// outside, the direction is a direction (dead rays carry d = 0), and the ray either misses the sphere or
+// enters it beyond tmin (with a margin that covers the rounding of these products): entry > tm  <=>
+// u = b - tm a > 0 and u^2 > disc.  NaN anywhere makes the comparisons false, so the element is tested.
+template <class T>
+DI typename LaneOf<T>::M sphere_beyond(const SphereTerms<T>& q, T tmin) {
+  const T zero = splat<T>(0.0f);
+  const T disc = q.b * q.b - q.a * q.cc;
+  const T tm = tmin * 1.0001f + 1e-3f;
+  const T u = q.b - tm * q.a;
+  const auto misses = or_(lt(disc, zero), le(q.b, zero));
+  const auto beyond = and_(gt(u, zero), gt(u * u, disc));
+  return and_(and_(gt(q.cc, zero), gt(q.a, splat<T>(1e-12f))), or_(misses, beyond));
 }
 
-DI float lane_min2(float v) { return v; }
-DI float lane_min2(f2 v) { return v.x < v.y ? v.x : v.y; }
+DI float first_comp(float v) { return v; }
+DI float first_comp(f2 v) { return v.x; }
 
 template <class T>
 DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
@@ -1248,17 +1260,17 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops,
     }
   } else {
     // Front-to-back over the elements, in the order the wavefront's first ray meets their bounding spheres
-    // (a heuristic: the rays of a wavefront are neighbours).  An element is skipped when, for every ray of the
-    // wavefront, its sphere lies beyond the nearest hit found so far; since any t of the element is at least
-    // the entry distance, a skipped element can neither win nor tie.  Every lane of the wavefront is active
+    // (a heuristic: the rays of a wavefront are neighbours; a NaN key only changes the order).  An element is
+    // skipped when, for every ray of the wavefront, its sphere is missed or entered beyond the nearest hit found
+    // so far; since any t of the element is at least the entry distance, a skipped element can neither win nor tie.  Every lane of the wavefront is active
     // here (the kernels clamp instead of masking), so lane e can hold the sort key of element e.
     const int lane = threadIdx.x & 63;
     float key = 0.0f;
     for (int e = 0; e < cull.n; ++e) {
       float k = -kInf;
       if (cull.R[e] >= 0.0f) {
-        const float mine = lane_min2(sphere_entry(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]));
-        k = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mine)));
+        const SphereTerms<T> q = sphere_terms(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
+        k = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(first_comp(q.b) - cull.R[e])));
       }
       key = lane == e ? k : key;
     }
@@ -1274,8 +1286,8 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops,
       const int e = __builtin_ctzll(pick ? pick : todo);
       todo &= ~(1ull << e);
       if (cull.R[e] >= 0.0f) {
-        const T lb = sphere_entry(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
-        if (__all(all_(gt(lb, tmin)))) continue;
+        const SphereTerms<T> q = sphere_terms(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
+        if (__all(all_(sphere_beyond(q, tmin)))) continue;
       }
       const int s0 = cull.first[e], s1 = s0 + cull.count[e];
       for (int s = s0; s < s1; ++s) {
