@@ -58,7 +58,7 @@ class SpotSizeLoss(Goal):
         from .. import kernels as K
         from .. import program as P
         from ..rays.ray import Rays
-        if not AG.needs_grad(scene.elements):
+        if not scene._needs_grad():
             return None
         prog = scene._program()
         slots = [int(r["sensor_slot"]) for r in prog if int(r["sensor_slot"]) >= 0

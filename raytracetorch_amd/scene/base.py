@@ -75,15 +75,24 @@ class Scene(nn.Module):
         self.register_buffer("map_to_surface", torch.tensor(sf, dtype=torch.long, device=device))
         self.total_surfaces = len(el)
 
-    def _program(self):
-        """Packed surface program of the current elements; re-packed only when an element list entry or a
-        parameter (identity, storage or version counter) changed since the last call."""
+    def _element_params(self):
+        """(ids of the elements, parameters of the scene), re-collected only when the element list changes:
+        walking the module tree costs more than launching a small trace."""
         els = tuple(id(el) for el in self.elements)
         plist = getattr(self, "_param_list", None)
         if plist is None or plist[0] != els:
-            plist = (els, list(self.parameters()))
+            plist = (els, list(self.elements.parameters()))
             self._param_list = plist
-        key = (els, tuple((p.data_ptr(), p._version) for p in plist[1]))
+        return plist
+
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self._element_params()[1])
+
+    def _program(self):
+        """Packed surface program of the current elements; re-packed only when an element list entry or a
+        parameter (identity, storage or version counter) changed since the last call."""
+        els, params = self._element_params()
+        key = (els, tuple((p.data_ptr(), p._version) for p in params))
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
             with torch.random.fork_rng(devices=[]):   # keys drawn while packing are replaced below

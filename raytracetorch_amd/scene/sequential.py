@@ -32,7 +32,7 @@ class SequentialScene(Scene):
                 rays._snapshot(hist[s])
             return rays
         from .. import autograd as AG
-        if AG.needs_grad(self.elements):
+        if self._needs_grad():
             # differentiable w.r.t. the scene parameters: the backward re-traces the input bundle, whose
             # planes stay untouched because the result goes into new tensors (nothing is written in place)
             from ..rays.ray import Rays
