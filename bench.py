@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "spot", "sample_trace"],
                     help="singlet = the headline line; the others time the remaining configurations (informational)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two "
+                                                      "ranks rehearse the multi-rank path on one GPU)")
     ap.add_argument("--graph", action="store_true",
                     help="singlet workload: capture one simulate() in a HIP graph and replay it per step (launch-bound sizes)")
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
@@ -210,17 +212,24 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
 
 def main():
     a = parse()
+    if os.environ.get("RTT_BENCH_WATCHDOG"):   # dump every thread's stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RTT_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # one rank per GPU on a full node
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     import raytracetorch_amd as rta
     import scenes
