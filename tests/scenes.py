@@ -226,6 +226,42 @@ def random_system(ns, rng):
     return els
 
 
+def random_system_extra(ns, rng):
+    """Random systems over the kinds random_system does not draw: ideal thin lenses, reflecting / refracting
+    boxes, triplets, rectangular and elliptic stops, parabolic and cylindrical mirrors."""
+    els = []
+    z = 0.0
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.choice(["ideal", "box_reflect", "box_refract", "triplet", "rect_stop", "ellipse_stop", "parabolic", "cyl_mirror"])
+        rot = [float(x) for x in rng.normal(0, 0.03, 3)] if rng.random() < 0.5 else None
+        tr = ns.RayTransform(translation=[float(rng.normal(0, 0.2)), float(rng.normal(0, 0.2)), z], rotation=rot)
+        if kind == "ideal":
+            els.append(ns.IdealThinLens(focal=float(rng.uniform(20.0, 80.0)) * (1 if rng.random() < 0.7 else -1),
+                                        diameter=float(rng.uniform(8.0, 14.0)), transform=tr))
+        elif kind in ("box_reflect", "box_refract"):
+            box = ns.Box(length=float(rng.uniform(2.0, 4.0)), width=float(rng.uniform(6.0, 14.0)),
+                         height=float(rng.uniform(6.0, 14.0)), transform=tr)
+            fn = ns.Reflect() if kind == "box_reflect" else ns.RefractSnell(1.0, float(rng.uniform(1.3, 1.8)))
+            els.append(ns.ElementCustom(box, fn, None))
+        elif kind == "triplet":
+            els.append(ns.TripletLens(c1=float(rng.uniform(0.0, 0.05)), c2=float(rng.uniform(-0.03, 0.0)),
+                                      c3=float(rng.uniform(0.0, 0.02)), c4=float(rng.uniform(-0.05, 0.0)), d=12.0,
+                                      t1=2.0, t2=1.0, t3=2.5, ior_glass1=1.5, ior_glass2=float(rng.uniform(1.55, 1.75)),
+                                      ior_glass3=1.55, transform=tr))
+        elif kind == "rect_stop":
+            els.append(ns.RectangularAperture(float(rng.uniform(1.5, 4.0)), float(rng.uniform(1.0, 3.0)), invert=True, transform=tr))
+        elif kind == "ellipse_stop":
+            els.append(ns.EllipticAperture(float(rng.uniform(2.5, 4.0)), float(rng.uniform(1.0, 2.0)), rot=float(rng.uniform(0, 1.5)),
+                                           invert=True, transform=tr))
+        elif kind == "parabolic":
+            els.append(ns.ParabolicMirror(c1=float(rng.uniform(-0.03, 0.03)), d=0.0, transform=tr))
+        else:
+            els.append(ns.CylindricalMirror(c1=float(rng.uniform(-0.03, 0.03)), d=0.0, transform=tr))
+        z += float(rng.uniform(6.0, 10.0))
+    els.append(ns.Sensor(ns.Disk(15.0, transform=ns.RayTransform(translation=[0.0, 0.0, z]))))
+    return els
+
+
 # ---------------------------------------------------------------------------------------------
 # ray-source cases (rays/bundle.py)
 # ---------------------------------------------------------------------------------------------

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("gen", ["random_system", "random_system_extra"])
 @pytest.mark.parametrize("seed", range(16))
-def test_random_system_sequential_and_nearest(ns, seed):
-    els = scenes.random_system(ns, np.random.default_rng(seed))
+def test_random_system_sequential_and_nearest(ns, seed, gen):
+    els = getattr(scenes, gen)(ns, np.random.default_rng(seed))
     torch.manual_seed(seed)
     rays = scenes.disk_bundle(ns, radius=5.0, z=-15.0, rot=[0.03 * math.sin(seed), 0.02, 0.0]).sample(3001)
     p0, d0, I0 = rays.pos.clone(), rays.dir.clone(), rays.intensity.clone()
@@ -32,7 +33,8 @@ def test_random_system_sequential_and_nearest(ns, seed):
     assert_parity(tm[clean].reshape(-1), tm_o[clean].reshape(-1), O.intersect_matrix(prog, p0, d0, dtype=torch.float64).numpy()[clean].reshape(-1),
                   what=f"seed {seed} t matrix")
     # sequential trace
-    out = ns.SequentialScene(els).simulate(rays.to(DEV))
+    with torch.no_grad():   # a Rectangle's half-widths are trainable by default, as in the reference
+        out = ns.SequentialScene(els).simulate(rays.to(DEV))
     o32 = O.trace_sequential(prog, p0, d0, I0)
     o64 = O.trace_sequential(prog, p0, d0, I0, dtype=torch.float64)
     same = (o32["intensity"].numpy() > 0) == (out.intensity.cpu().numpy() > 0)
@@ -52,5 +54,9 @@ def test_random_system_sequential_and_nearest(ns, seed):
     srt = np.sort(tm_o, axis=1)
     tie = np.isfinite(srt[:, 1]) & (np.abs(srt[:, 1] - srt[:, 0]) <= 1e-4 * np.abs(srt[:, 0]))
     ok = clean & ~tie
-    assert_parity(scene.rays.pos.cpu().numpy()[ok], o["pos"].numpy()[ok], tol=2e-5, what=f"seed {seed} step pos")
+    # near-axial rays on a paraboloid cancel in -B - sqrt(disc): two float32 evaluations differ by 1e-4 there and
+    # are judged against the float64 evaluation, like the sequential trace above
+    o64s = O.step_nearest(prog, p0, d0, I0, dtype=torch.float64)
+    assert_parity(scene.rays.pos.cpu().numpy()[ok], o["pos"].numpy()[ok], o64s["pos"].numpy()[ok], tol=2e-5,
+                  what=f"seed {seed} step pos")
     assert np.array_equal((scene.rays.intensity.cpu().numpy() > 0)[ok], (o["intensity"].numpy() > 0)[ok])

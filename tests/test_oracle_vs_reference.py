@@ -18,12 +18,13 @@ import raytracetorch_amd.program as P
 pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
 
 
+@pytest.mark.parametrize("gen", ["random_system", "random_system_extra"])
 @pytest.mark.parametrize("seed", range(12))
-def test_oracle_matches_live_reference(seed):
+def test_oracle_matches_live_reference(seed, gen):
     ref = scenes.namespace_from_package(ref_loader.load())
     mine = scenes.namespace_from_package(rta)
-    els_ref = scenes.random_system(ref, np.random.default_rng(seed))
-    els_mine = scenes.random_system(mine, np.random.default_rng(seed))
+    els_ref = getattr(scenes, gen)(ref, np.random.default_rng(seed))
+    els_mine = getattr(scenes, gen)(mine, np.random.default_rng(seed))
     torch.manual_seed(seed)
     rays = scenes.disk_bundle(ref, radius=5.0, z=-15.0, rot=[0.03 * math.sin(seed), 0.02, 0.0]).sample(768)
     p0, d0, I0 = rays.pos.clone(), rays.dir.clone(), rays.intensity.clone()
