@@ -36,10 +36,12 @@ def parse():
     ap.add_argument("--rays", type=int, default=64 * 2 ** 20, help="rays per GPU")
     ap.add_argument("--cpu-rays", type=int, default=2 ** 24, help="rays of the CPU-baseline sample (about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "spot", "sample_trace"],
+    ap.add_argument("--workload", default="singlet", choices=["singlet", "system5", "naive32", "naive_sim", "spot", "sample_trace"],
                     help="singlet = the headline line; the others time the remaining configurations (informational)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two "
                                                       "ranks rehearse the multi-rank path on one GPU)")
+    ap.add_argument("--step-loop", action="store_true",
+                    help="naive_sim workload: one launch per bounce (the reference's loop) instead of the fused bounce loop")
     ap.add_argument("--graph", action="store_true",
                     help="singlet workload: capture one simulate() in a HIP graph and replay it per step (launch-bound sizes)")
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
@@ -111,7 +113,8 @@ def cpu_baseline(n, scenes, ns):
 def other_workload(a, ns, scenes, dev, rank, world, dist):
     """Configurations 3-5: 5-element system (16 Mi rays), 32-surface nearest-hit step (4 Mi rays), spot-size
     loss forward+backward (singlet + sensor).  Same timing discipline as the headline line."""
-    defaults = {"system5": 16 * 2 ** 20, "naive32": 4 * 2 ** 20, "spot": 32 * 2 ** 20, "sample_trace": 64 * 2 ** 20}
+    defaults = {"system5": 16 * 2 ** 20, "naive32": 4 * 2 ** 20, "spot": 32 * 2 ** 20, "sample_trace": 64 * 2 ** 20,
+                "naive_sim": 4 * 2 ** 20}
     n = a.rays if a.rays != 64 * 2 ** 20 else defaults[a.workload]
     pos, d = device_bundle(n, dev, 1000, offset=rank * n, ns=ns)
     mk = lambda p, q: ns.Rays.from_planes(p, q, torch.ones(n, device=dev), torch.zeros(n, device=dev, dtype=torch.int8),
@@ -140,6 +143,27 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         def step():
             scene.simulate(bundle.sample(n, offset=rank * n, seed=7))
         bytes_per_ray = 33 + 56
+    elif a.workload == "naive_sim":
+        # Scene.simulate() of the 32-surface scene with the reference's default of 100 bounces
+        scene = ns.Scene()
+        for el in scenes.naive32(ns):
+            scene.add_element(el)
+        rays._pos[2].fill_(-10.0)
+        surfaces = 32
+        kernel = "k_simulate_nearest (launch per bounce)" if a.step_loop else "k_simulate_nearest (fused bounce loop)"
+
+        def step():
+            scene.elements[-1].reset()
+            scene.rays = rays.clone()
+            if a.step_loop:
+                scene._build_index_maps()
+                for _ in range(scene.Nbounces):
+                    if not (scene.rays.intensity > 0).any():
+                        break
+                    scene.step()
+            else:
+                scene.simulate()
+        bytes_per_ray = 56
     elif a.workload == "naive32":
         scene = ns.Scene()
         for el in scenes.naive32(ns):
@@ -147,7 +171,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         rays._pos[2].fill_(-10.0)
         work = rays.clone()
         surfaces = 32
-        kernel = "k_step_nearest"
+        kernel = "k_simulate_nearest (one bounce)"
 
         def step():
             work._pos.copy_(rays._pos); work._dir.copy_(rays._dir); work.intensity.copy_(rays.intensity)

@@ -182,6 +182,20 @@ int rtt_render_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
                    const float* base_rgb, uint64_t skip_mask, const float light_dir[3],
                    const float background[3], float* rgb, void* stream);
 
+/* ---- the whole bounce loop: Scene.simulate (scene/base.py:129-142) -------------------------------
+ * Up to max_bounces repetitions of Scene.step in one launch, each ray running its own loop in registers (a ray
+ * that misses, or whose intensity is 0, is not touched by later bounces, so stopping it early changes nothing).
+ * bounces[i] (nullable) = number of surfaces ray i interacted with.  Sensor hits are appended, in no particular
+ * order, to hit_list[k] = (hit_local x, y, z, intensity before the surface) with hit_keys[k] =
+ * (bounce * RTT_MAX_SURFACES + sensor_slot, ray index); *hit_count (zeroed by the caller) counts every hit
+ * offered, also those beyond hit_capacity, which are dropped: a caller that finds *hit_count > hit_capacity
+ * repeats the call with more room.  Sorting the keys restores the reference's order (by bounce, then by ray). */
+int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                             float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                             const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
+                             int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
+                             int64_t hit_capacity, void* stream);
+
 /* ---- Element.intersectTest (elements/parent.py:30-42; geom/shape.py:25-59; primitives.py:38-57)
  * t_out[s*ld_t + i] = distance to surface s of the program, inf on a miss. */
 int rtt_intersect_test_f32(const float* pos, const float* dir, int64_t ld, int64_t n,

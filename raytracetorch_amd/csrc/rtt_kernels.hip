@@ -134,6 +134,8 @@ DI f2 quot_refined(f2 a, f2 b) {
 template <class T> DI T splat(float v) { return T(v); }
 DI float comp(float a, int) { return a; }
 DI float comp(f2 a, int k) { return k == 0 ? a.x : a.y; }
+DI bool set_mask(bool, int, bool v) { return v; }
+DI b2 set_mask(b2 m, int k, bool v) { return k == 0 ? b2{v, m[1]} : b2{m[0], v}; }
 DI bool mcomp(bool m, int) { return m; }
 DI bool mcomp(b2 m, int k) { return k == 0 ? m[0] : m[1]; }
 
@@ -849,6 +851,11 @@ struct SensorIO {
   uint8_t* mask;
   int64_t ld;
   int64_t index0;  // index in the call of the ray that element 0 of these (possibly tile-shifted) planes holds
+  // append mode (multi-bounce kernel): hits go to a compact list instead of the dense per-ray slots
+  float* app_hit;      // [cap][4]: hit_local x, y, z and the intensity before the surface
+  int32_t* app_key;    // [cap][2]: bounce * RTT_MAX_SURFACES + sensor slot, index of the ray in the call
+  int32_t* app_count;  // number of hits offered so far (may exceed cap: the host then retries with more room)
+  int32_t app_cap, bounce;
 };
 
 template <class T>
@@ -902,6 +909,23 @@ DI void store_ray(const RayIO& io, I i, const Ray<T>& r, bool vec = false, int n
 
 template <class T, class M, class IX>
 DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, int nv) {
+  if (se.app_count) {
+#pragma unroll
+    for (int k = 0; k < LaneOf<T>::N; ++k) {
+      if (k >= nv || !mcomp(hit, k)) continue;
+      const int at = atomicAdd(se.app_count, 1);
+      if (at < se.app_cap) {
+        float* h = se.app_hit + 4 * (int64_t)at;
+        h[0] = comp(hl.x, k);
+        h[1] = comp(hl.y, k);
+        h[2] = comp(hl.z, k);
+        h[3] = comp(I, k);
+        se.app_key[2 * (int64_t)at] = se.bounce * RTT_MAX_SURFACES + slot;
+        se.app_key[2 * (int64_t)at + 1] = (int32_t)(se.index0 + (int64_t)i + k);
+      }
+    }
+    return;
+  }
   const int64_t base = (int64_t)slot * se.ld;  // wave-uniform: the slot's planes are addressed by pointer
   uint8_t* mask = se.mask + base;
   float* hx = se.hit + 3 * base;
@@ -1250,7 +1274,8 @@ DI float first_comp(f2 v) { return v.x; }
 
 template <class T>
 DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
-                typename WinOf<T>::type& win, const Cull& cull, uint64_t skip = 0) {
+                typename WinOf<T>::type& win, const Cull& cull, uint64_t skip = 0,
+                const typename LaneOf<T>::M* act = nullptr) {
   tmin = splat<T>(kInf);
   win = typename WinOf<T>::type(0x7fffffff);
   if (cull.n == 0) {
@@ -1287,7 +1312,10 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops,
       todo &= ~(1ull << e);
       if (cull.R[e] >= 0.0f) {
         const SphereTerms<T> q = sphere_terms(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
-        if (__all(all_(sphere_beyond(q, tmin)))) continue;
+        // rays that take no part in this search (`act` false) do not hold an element back
+        auto beyond = sphere_beyond(q, tmin);
+        if (act) beyond = or_(beyond, not_(*act));
+        if (__all(all_(beyond))) continue;
       }
       const int s0 = cull.first[e], s1 = s0 + cull.count[e];
       for (int s = s0; s < s1; ++s) {
@@ -1372,11 +1400,20 @@ DI void ray_set(Ray<f2>& r, int k, const Ray<float>& v) {
   }
 }
 
+// Scene.simulate (scene/base.py:129-142) as ONE launch: every ray runs its own bounce loop in registers.
+// The reference stops all rays together when none carries intensity; per ray that is the same thing, because
+// a ray without a hit, or with intensity 0, is not touched by any later bounce (scene/base.py:201-235), so a
+// lane leaves the loop when its ray missed or died.  HBM sees 28 B in and 28 B out per ray for the whole
+// simulate instead of per bounce; sensor hits go to an append list keyed by (bounce, slot, ray).
+// Scene.step (scene/base.py:180-235) is the same kernel with max_bounces = 1, dense sensor slots and the
+// winners of the cast written out, so a loop of steps and one simulate run the same machine code per bounce.
 template <class T>
-__global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                         Ops ops, Cull cull, int32_t* __restrict__ winner, SensorIO se,
-                                                         int vec) {
+__global__ void __launch_bounds__(kBlock) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                             Ops ops, Cull cull, int max_bounces,
+                                                             int32_t* __restrict__ winner,
+                                                             int32_t* __restrict__ bounces_out, SensorIO se, int vec) {
   constexpr int N = LaneOf<T>::N;
+  using M = typename LaneOf<T>::M;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
   const int64_t rounds = (io.n + stride - 1) / stride;
@@ -1386,21 +1423,56 @@ __global__ void __launch_bounds__(kBlock) k_step_nearest(RayIO io, const RttSurf
     const int64_t i = live ? want : 0;
     const int nv = (io.n - i) >= N ? N : 1;
     Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
-    T tmin;
-    typename WinOf<T>::type win;
-    nearest<T>(prog, n_surf, ops, r.p, r.d, tmin, win, cull);
-    if (!live) continue;
+    bool open[N];   // the ray may still move: it has not missed yet
+    int taken[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      if (k < nv) {
+      open[k] = live && k < nv;
+      taken[k] = 0;
+    }
+    SensorIO seb = se;
+    for (int b = 0; b < max_bounces; ++b) {
+      M act = mask_all<M>(false);
+      bool any_act = false;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const bool a = open[k] && comp(r.I, k) > 0.0f;
+        any_act |= a;
+        act = set_mask(act, k, a);
+      }
+      if (!__any(any_act)) break;
+      T tmin;
+      typename WinOf<T>::type win;
+      // when the cast result is wanted for every ray (also those without intensity), no ray is left out of
+      // the culling decisions
+      nearest<T>(prog, n_surf, ops, r.p, r.d, tmin, win, cull, 0, (winner && b == 0) ? nullptr : &act);
+      seb.bounce = b;
+      if (winner && b == 0 && live) {  // Scene.ray_cast result of the first bounce, for every ray
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (k < nv) winner[i + k] = icomp(win, k);
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        if (!mcomp(act, k)) continue;
         const int wk = icomp(win, k);
-        if (winner) winner[i + k] = wk;
+        if (wk < 0) {
+          open[k] = false;
+          continue;
+        }
         Ray<float> rk = ray_comp(r, k);
-        serve_winner(prog, ops, wk, comp(tmin, k), rk, se, i + k);
+        serve_winner(prog, ops, wk, comp(tmin, k), rk, seb, i + k);
         ray_set(r, k, rk);
+        ++taken[k];
       }
     }
+    if (!live) continue;
     store_ray<T>(io, i, r, vec != 0, nv);
+    if (bounces_out) {
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (k < nv) bounces_out[i + k] = taken[k];
+    }
   }
 }
 
@@ -2078,8 +2150,8 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
-  hipLaunchKernelGGL(k_step_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
-                     n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), winner, se, vec);
+  hipLaunchKernelGGL(k_simulate_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+                     n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), 1, winner, (int32_t*)nullptr, se, vec);
   return launch_status();
 }
 
@@ -2164,6 +2236,39 @@ int rtt_trace_seq_history_f32(const float* pos_in, const float* dir_in, const fl
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld, 0};
   hipLaunchKernelGGL(k_trace_seq_history, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev, n_surf, se,
                      hist_pos, hist_any, hist_ld);
+  return launch_status();
+}
+
+int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                             float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                             const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
+                             int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
+                             int64_t hit_capacity, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev) return RTT_E_NULL;
+  if (n < 0 || n > 0x7fffffff || ld_in < n || ld_out < n || max_bounces < 0 || hit_capacity < 0 ||
+      hit_capacity > 0x7fffffff)
+    return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out) || misaligned(bounces) || misaligned(hit_list) || misaligned(hit_keys) || misaligned(hit_count))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (!prog_host) any_sensor = hit_count != nullptr;
+  if (any_sensor && (!hit_count || (hit_capacity > 0 && (!hit_list || !hit_keys)))) return RTT_E_NULL;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+  SensorIO se = {};
+  se.app_hit = hit_list;
+  se.app_key = hit_keys;
+  se.app_count = any_sensor ? hit_count : nullptr;
+  se.app_cap = (int32_t)hit_capacity;
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
+                  aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+  hipLaunchKernelGGL(k_simulate_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+                     n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces,
+                     se, vec);
   return launch_status();
 }
 

@@ -34,6 +34,13 @@ class Sensor(Element):
     def _record_dense(self, hit_planes, w, mask, ids):
         self._dense.append((hit_planes, w, mask, ids))
 
+    def _record_hits(self, locs, w, ids):
+        """One list entry of already compacted hits (rows in ray order)."""
+        self._flush()
+        self._locs.append(locs)
+        self._inten.append(w)
+        self._ids.append(ids)
+
     def _flush(self):
         for hit, w, mask, ids in self._dense:
             m = mask.bool()

@@ -159,6 +159,46 @@ def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bo
     return winner, sens_hit, sens_w, sens_mask
 
 
+def simulate_nearest(rays: Rays, prog: np.ndarray, max_bounces: int, want_bounces: bool = False,
+                     first_capacity: int = None):
+    """Scene.simulate in one launch (every ray runs its own bounce loop in registers), in place.
+    Returns (bounces [N] int32 or None, hits) where hits is None for a program without sensors, else
+    (hit [M,4] = hit_local xyz + intensity before the surface, keys [M,2] = (bounce*64 + slot, ray index)),
+    unsorted.  The ray planes are replaced only after the hit list is known to be complete."""
+    n = _check_rays(rays)
+    dev = rays.device
+    bounces = torch.zeros((n,), device=dev, dtype=torch.int32) if want_bounces else None
+    has_sensor = P.n_sensor_slots(prog) > 0
+    if n == 0 or prog.shape[0] == 0 or max_bounces <= 0:
+        empty = (torch.empty((0, 4), device=dev), torch.empty((0, 2), device=dev, dtype=torch.int32))
+        return bounces, (empty if has_sensor else None)
+    dp = N.DeviceProgram.upload(prog, dev)
+    out_pos, out_dir, out_int = torch.empty_like(rays._pos), torch.empty_like(rays._dir), torch.empty_like(rays.intensity)
+    cap = (2 * n if first_capacity is None else int(first_capacity)) if has_sensor else 0
+    while True:
+        hit = torch.empty((cap, 4), device=dev, dtype=torch.float32) if has_sensor else None
+        keys = torch.empty((cap, 2), device=dev, dtype=torch.int32) if has_sensor else None
+        count = torch.zeros((1,), device=dev, dtype=torch.int32) if has_sensor else None
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_simulate_nearest_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+                N.ptr(out_pos), N.ptr(out_dir), N.ptr(out_int), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(bounces),
+                N.ptr(hit), N.ptr(keys), N.ptr(count), cap, N.stream_handle(dev))
+        N.check(code, "rtt_simulate_nearest_f32")
+        if not has_sensor:
+            break
+        m = int(count.item())
+        if m <= cap:
+            hit, keys = hit[:m], keys[:m]
+            break
+        cap = m     # more sensor crossings than room: trace again from the untouched input
+        if bounces is not None:
+            bounces.zero_()
+    rays._pos, rays._dir, rays.intensity = out_pos, out_dir, out_int
+    return bounces, ((hit, keys) if has_sensor else None)
+
+
 def apply_physics(rec: np.ndarray, hit_local, ray_dir, normal):
     """One physics functor on [N,3] tensors -> (new_dir [N,3], imult [N])."""
     N.require_device(hit_local, ray_dir, normal)

@@ -124,10 +124,34 @@ class Scene(nn.Module):
         if self.rays is None:
             return
         self._build_index_maps()
-        for _ in range(self.Nbounces):
-            if not (self.rays.intensity > 0).any():
-                break
-            self.step()
+        if hasattr(self.rays, "_snapshot") or len(self.elements) == 0:
+            # rays wrapped in Paths want a snapshot per bounce: one launch per bounce, like the reference
+            for _ in range(self.Nbounces):
+                if not (self.rays.intensity > 0).any():
+                    break
+                self.step()
+            return
+        # the whole bounce loop in one launch: a ray that misses or dies is not touched by later bounces, so
+        # letting each ray stop on its own gives what the reference's lock-step loop gives
+        prog = self._program()
+        _, hits = K.simulate_nearest(self.rays, prog, self.Nbounces, first_capacity=getattr(self, "_hit_capacity", None))
+        if hits is not None:
+            self._deliver_sensor_hits(prog, self.rays, *hits)
+
+    def _deliver_sensor_hits(self, prog, rays, hit, keys):
+        """Hand an unsorted hit list to the sensors as the reference's per-bounce list entries: one entry per
+        bounce in which the sensor was hit, rows in ray order (elements/sensor.py:35-37 under scene/base.py:213-226)."""
+        if hit.shape[0] == 0:
+            return
+        order = torch.argsort(keys[:, 0].to(torch.int64) * (len(rays) + 1) + keys[:, 1].to(torch.int64))
+        hit, keys = hit[order], keys[order]
+        group, ray = keys[:, 0].to(torch.int64), keys[:, 1].to(torch.int64)
+        starts = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=group.device), group[1:] != group[:-1]])).flatten()
+        bounds = starts.tolist() + [int(group.shape[0])]
+        slot_of = {int(rec["sensor_slot"]): self.elements[int(rec["element_id"])] for rec in prog if int(rec["sensor_slot"]) >= 0}
+        heads = group[starts].tolist()
+        for a, b, g in zip(bounds[:-1], bounds[1:], heads):
+            slot_of[g % P.MAX_SURFACES]._record_hits(hit[a:b, :3], hit[a:b, 3], rays.id[ray[a:b]])
 
     def ray_cast(self, rays):
         """(hit_mask [N], winner_element_ids [N], winner_surf_ids [N]) or None when nothing is hit

@@ -286,3 +286,54 @@ def test_culling_never_changes_the_nearest_hit(ns):
             tie = np.isfinite(srt[:, 1]) & (np.abs(srt[:, 1] - srt[:, 0]) <= 1e-4 * np.maximum(1.0, np.abs(srt[:, 0])))
         agree = (res[1][0].cpu().numpy() == wo.numpy()) | tie
         assert agree.mean() > 0.999, (order, agree.mean())
+
+
+def _step_loop(scene):
+    """Scene.simulate as the reference writes it (scene/base.py:129-142): one launch per bounce."""
+    scene._build_index_maps()
+    for _ in range(scene.Nbounces):
+        if not (scene.rays.intensity > 0).any():
+            break
+        scene.step()
+
+
+@pytest.mark.parametrize("case", ["naive32", "cavity"])
+def test_fused_bounce_loop_equals_the_step_loop(ns, case):
+    """Scene.simulate runs every ray's bounce loop in one launch; rays and sensor lists are bit-identical with
+    the launch-per-bounce loop, including a cavity whose rays cross the sensor again and again and a first hit-list
+    capacity that is too small (which forces the retry from the untouched input)."""
+    from util import golden, rays_from_golden
+    g = golden("naive32")
+    rays = rays_from_golden(ns, g, device=DEV)
+    T = lambda z: ns.RayTransform(translation=[0.0, 0.0, z])
+
+    def build():
+        scene = ns.Scene()
+        if case == "naive32":
+            els = scenes.naive32(ns)
+            scene.Nbounces = 7
+        else:   # two facing mirrors with a transmitting sensor between them
+            els = [ns.SphericalMirror(c1=-0.002, d=0.0, diameter=40.0, transform=T(60.0)),
+                   ns.SphericalMirror(c1=0.002, d=0.0, diameter=40.0, transform=T(-20.0)),
+                   ns.Sensor(ns.Disk(30.0, transform=T(20.0)))]
+            scene.Nbounces = 12
+        for el in els:
+            scene.add_element(el)
+        return scene
+
+    a, b = build(), build()
+    a.rays, b.rays = rays.clone(), rays.clone()
+    if case == "cavity":
+        a._hit_capacity = 100
+    a.simulate()
+    _step_loop(b)
+    for x, y in ((a.rays._pos, b.rays._pos), (a.rays._dir, b.rays._dir), (a.rays.intensity, b.rays.intensity)):
+        assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
+    sa, sb = a.elements[-1], b.elements[-1]
+    assert len(sa.hitLocs) == len(sb.hitLocs) > 0
+    for la, lb in zip(sa.hitLocs, sb.hitLocs):
+        assert torch.equal(la, lb)
+    for ta, tb in zip(sa.getHitsTensors(), sb.getHitsTensors()):
+        assert torch.equal(ta, tb)
+    if case == "cavity":
+        assert sa.getHitsTensors()[0].shape[0] > len(rays) and len(sa.hitLocs) > 2    # several crossings per ray
