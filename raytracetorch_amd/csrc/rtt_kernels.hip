@@ -1407,9 +1407,9 @@ DI void ray_set(Ray<f2>& r, int k, const Ray<float>& v) {
 // simulate instead of per bounce; sensor hits go to an append list keyed by (bounce, slot, ray).
 // Scene.step (scene/base.py:180-235) is the same kernel with max_bounces = 1, dense sensor slots and the
 // winners of the cast written out, so a loop of steps and one simulate run the same machine code per bounce.
-template <class T>
-__global__ void __launch_bounds__(kBlock) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                             Ops ops, Cull cull, int max_bounces,
+template <class T, bool SINGLE>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                             Ops ops, Cull cull, int max_bounces_,
                                                              int32_t* __restrict__ winner,
                                                              int32_t* __restrict__ bounces_out, SensorIO se, int vec) {
   constexpr int N = LaneOf<T>::N;
@@ -1431,6 +1431,7 @@ __global__ void __launch_bounds__(kBlock) k_simulate_nearest(RayIO io, const Rtt
       taken[k] = 0;
     }
     SensorIO seb = se;
+    const int max_bounces = SINGLE ? 1 : max_bounces_;  // SINGLE: Scene.step, the loop folds away
     for (int b = 0; b < max_bounces; ++b) {
       M act = mask_all<M>(false);
       bool any_act = false;
@@ -1452,7 +1453,9 @@ __global__ void __launch_bounds__(kBlock) k_simulate_nearest(RayIO io, const Rtt
         for (int k = 0; k < N; ++k)
           if (k < nv) winner[i + k] = icomp(win, k);
       }
-#pragma unroll
+      // one copy of the winner dispatch serves both packed components in turn (the dispatch is the bulk of the
+      // kernel's code and registers)
+#pragma unroll 1
       for (int k = 0; k < N; ++k) {
         if (!mcomp(act, k)) continue;
         const int wk = icomp(win, k);
@@ -2150,7 +2153,7 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
-  hipLaunchKernelGGL(k_simulate_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+  hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
                      n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), 1, winner, (int32_t*)nullptr, se, vec);
   return launch_status();
 }
@@ -2266,7 +2269,7 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
-  hipLaunchKernelGGL(k_simulate_nearest<f2>, dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+  hipLaunchKernelGGL((k_simulate_nearest<f2, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
                      n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces,
                      se, vec);
   return launch_status();
