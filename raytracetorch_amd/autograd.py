@@ -31,6 +31,20 @@ TAN_SLOTS = 32  # Rs[9] ts[3] Rj[9] tj[3] geom[4] phys[4]
 _SLOT_ORDER = (("Rs", 9), ("ts", 3), ("Rj", 9), ("tj", 3), ("geom", 4), ("phys", 4))
 
 
+_mask_cache = {}
+
+
+def _mask_list(mask: torch.Tensor):
+    """Host copy of a gradient mask; masks are constant buffers, so a device-resident one is fetched once."""
+    key = (id(mask), mask.data_ptr(), mask._version)
+    hit = _mask_cache.get(key)
+    if hit is None:
+        if len(_mask_cache) > 1024:
+            _mask_cache.clear()
+        hit = _mask_cache[key] = mask.reshape(-1).tolist()
+    return hit
+
+
 def trainable_scalars(elements) -> List[Tuple[torch.nn.Parameter, int]]:
     """(parameter, flat index) for every trainable scalar of the elements, shared Parameters once.
     Components that a gradient mask (trans_mask / rot_mask) zeroes anyway are skipped."""
@@ -48,8 +62,9 @@ def trainable_scalars(elements) -> List[Tuple[torch.nn.Parameter, int]]:
                 continue
             seen.add(id(p))
             mask = masks.get(id(p))
+            keep = None if mask is None else _mask_list(mask)
             for i in range(p.numel()):
-                if mask is None or float(mask.reshape(-1)[i]) != 0.0:
+                if keep is None or keep[i] != 0.0:
                     out.append((p, i))
     return out
 
@@ -76,10 +91,19 @@ def tangent_table(elements, thetas) -> np.ndarray:
         if id(p) not in index_of:
             index_of[id(p)] = len(params)
             params.append(p)
-    y = torch.cat([r[2].cpu() for r in rows])
-    eye = torch.eye(y.numel(), dtype=y.dtype)
+    # the slot expressions live where the parameters live; everything comes to the host in one transfer
+    home = rows[0][2].device
+    y = torch.cat([r[2].to(home) for r in rows])
+    eye = torch.eye(y.numel(), dtype=y.dtype, device=home)
     jac = torch.autograd.grad(y, params, grad_outputs=eye, is_grads_batched=True, allow_unused=True)
-    jac = [None if g is None else g.reshape(y.numel(), -1).cpu().numpy() for g in jac]
+    widths = [p.numel() for p in params]
+    flat = torch.cat([torch.zeros((y.numel(), w), dtype=y.dtype, device=home) if g is None else g.reshape(y.numel(), -1).to(home)
+                      for g, w in zip(jac, widths)], dim=1).cpu().numpy()
+    used = [g is not None for g in jac]
+    jac, at = [], 0
+    for w, u in zip(widths, used):
+        jac.append(flat[:, at:at + w] if u else None)
+        at += w
     pos = 0
     for surf, off, t in rows:
         w = t.numel()

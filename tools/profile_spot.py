@@ -15,9 +15,11 @@ import scenes  # noqa: E402
 
 ns = scenes.namespace_from_package(rta)
 dev = torch.device("cuda", 0)
-n = 32 * 2 ** 20
+n = 16 * 2 ** 20
 lens, sensor = scenes.spot_system(ns, grads=True)
 scene = ns.SequentialScene([lens, sensor])
+if "--device-params" in sys.argv:   # parameters resident on the GPU, as load_scene leaves them
+    scene.to(dev)
 bundle = ns.CollimatedDisk(radius=4.0, ray_id=0, device=dev, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(dev))
 rays = bundle.sample(n, seed=1)
 
@@ -51,4 +53,4 @@ for _ in range(20):
     step()
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
