@@ -185,6 +185,33 @@ def gen_grad_kats(ns):
     print("grad_kats:", {k: v.tolist() for k, v in out.items()})
 
 
+def gen_grad_tilt(ns):
+    """Gradients of a posed singlet + sensor with every pose component trainable, by the reference's autograd in
+    float32 and float64: once with the lens rotation exactly zero (tilt sensitivity at the nominal pose) and once
+    tilted.  Objective: fixed random projections of the output rays and of the sensor hit positions."""
+    torch.manual_seed(3)
+    n = 2048
+    rays = scenes.disk_bundle(ns, radius=3.5, rot=[0.02, 0.01, 0.0]).sample(n)
+    wp, wd, ws = torch.randn(n, 3), torch.randn(n, 3), torch.randn(n, 3)
+    out = rays_arrays(rays, "in_")
+    out.update(wp=npy(wp), wd=npy(wd), ws=npy(ws))
+    for tag, rot in (("zero", [0.0, 0.0, 0.0]), ("tilted", [0.03, -0.02, 0.1])):
+        for dtype, dt in ((torch.float32, "f32"), (torch.float64, "f64")):
+            lens, sensor = scenes.tilt_system(ns, rot)
+            if dtype == torch.float64:
+                lens.double(); sensor.double()
+            r = ns.Rays.initialize(rays.pos.to(dtype), rays.dir.to(dtype), dtype=dtype)
+            r = ns.SequentialScene([lens, sensor]).simulate(r)
+            locs, w, _ = sensor.getHitsTensors()
+            obj = (r.pos * wp.to(dtype)).sum() + (r.dir * wd.to(dtype)).sum() + (locs * ws.to(dtype) * w[:, None]).sum()
+            obj.backward()
+            got = scenes.tilt_gradients(lens, sensor)
+            out.update({f"{tag}_{dt}_{k}": npy(v) for k, v in got.items()})
+            out[f"{tag}_{dt}_obj"] = npy(obj)
+            print("grad_tilt", tag, dt, float(obj), {k: np.round(npy(v), 4).tolist() for k, v in got.items()})
+    np.savez_compressed(os.path.join(OUT, "grad_tilt.npz"), **out)
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed: Uniform.sample((N,))
     on [1]-shaped bounds draws torch.rand((N, 1)) once per distribution, in the order the code samples."""
@@ -302,6 +329,8 @@ def main():
     ns = scenes.namespace_from_package(ref)
     if sys.argv[1:] == ["bundles"]:
         return gen_bundles(ns)
+    if sys.argv[1:] == ["tilt"]:
+        return gen_grad_tilt(ns)
     if sys.argv[1:] == ["physics"]:
         return gen_physics(ns)
     if sys.argv[1:] == ["paths"]:
@@ -320,6 +349,7 @@ def main():
     gen_spot(ns, torch.float32, "f32")
     gen_spot(ns, torch.float64, "f64")
     gen_grad_kats(ns)
+    gen_grad_tilt(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

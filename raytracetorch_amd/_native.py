@@ -119,10 +119,10 @@ class DeviceProgram:
         self.dev = dev
 
     @classmethod
-    def upload(cls, prog: np.ndarray, device) -> "DeviceProgram":
+    def upload(cls, prog: np.ndarray, device, tag: str = "") -> "DeviceProgram":
         device = torch.device(device)
         prog = np.ascontiguousarray(prog)
-        key = (device.index if device.index is not None else torch.cuda.current_device(), prog.shape[0])
+        key = (device.index if device.index is not None else torch.cuda.current_device(), prog.shape[0], tag)
         raw = prog.tobytes()
         hit = cls._cache.get(key)
         if hit is not None and hit[0] == raw:

@@ -115,6 +115,20 @@ def tangent_table(elements, thetas) -> np.ndarray:
     return table
 
 
+def _tangent_program(prog, table, dev):
+    """The records the tangent kernels read.  A rotation that is exactly the identity lets the kernels skip the
+    matrix product, which is right for the value but drops d(R)/d(theta): where the table carries a non-zero
+    rotation tangent the identity flag is cleared (x*1 + y*0 + z*0 == x, so the primal values do not change)."""
+    flags = prog["flags"].copy()
+    flags[np.any(table[:, 0:9, :] != 0.0, axis=(1, 2))] &= ~np.int32(P.F_SHAPE_ROT_ID)
+    flags[np.any(table[:, 12:21, :] != 0.0, axis=(1, 2))] &= ~np.int32(P.F_SURF_ROT_ID)
+    if np.array_equal(flags, prog["flags"]):
+        return N.DeviceProgram.upload(prog, dev)
+    prog = prog.copy()
+    prog["flags"] = flags
+    return N.DeviceProgram.upload(prog, dev, tag="tangent")
+
+
 def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     """sum_i <adjoint_i, d out_i / d theta_k> for all theta, at most 8 directions per launch."""
     n = len(rays_in)
@@ -123,7 +137,7 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     out = torch.zeros(n_theta, dtype=torch.float64, device=dev)
     if n == 0 or n_theta == 0:
         return out
-    dp = N.DeviceProgram.upload(prog, dev)
+    dp = _tangent_program(prog, table, dev)
     fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
     adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
     for k0, used, padded in _chunks(table):  # kernels exist for 2, 4, 6 and 8 directions
@@ -278,7 +292,7 @@ class FusedSpotLossFn(torch.autograd.Function):
         rays_in, prog, table, thetas, group, centroid, slot, cx, cy, W = ctx.state
         n, dev = len(rays_in), rays_in.device
         dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
-        dp = N.DeviceProgram.upload(prog, dev)
+        dp = _tangent_program(prog, table, dev)
         for k0, used, padded in _chunks(table):
             width = padded.shape[2]
             tan_dev = torch.from_numpy(padded).to(dev)

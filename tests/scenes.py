@@ -90,6 +90,24 @@ def spot_system(ns, grads=True):
     return lens, sensor
 
 
+def tilt_system(ns, rot):
+    """Singlet whose element pose (translation and rotation), curvatures and indices are all trainable, and a sensor
+    whose pose is trainable too."""
+    lens = singlet(ns, c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True, ior_media_grad=True,
+                   transform=ns.RayTransform(translation=[0.2, -0.1, 1.0], rotation=rot, trans_grad=True, rot_grad=True))
+    sensor = ns.Sensor(ns.Disk(8.0, transform=ns.RayTransform(translation=[0.0, 0.0, 19.0], rotation=[0.0, 0.0, 0.0],
+                                                              trans_grad=True, rot_grad=True)))
+    return lens, sensor
+
+
+def tilt_gradients(lens, sensor):
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    return dict(lens_rot=lens.shape.transform.rot_vec.grad, lens_trans=lens.shape.transform.trans.grad,
+                c1=s0.c.grad, c2=s1.c.grad, t1=s1.transform.trans.grad, ior_glass=lens.ior_glass.grad,
+                ior_media=lens.ior_media.grad, sensor_rot=sensor.shape.transform.rot_vec.grad,
+                sensor_trans=sensor.shape.transform.trans.grad)
+
+
 # name -> (elements builder, rays builder, n_rays)
 def sequential_cases(ns):
     hp = math.pi / 2
