@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTT_ABI_VERSION 2
+#define RTT_ABI_VERSION 3
 #define RTT_MAX_SURFACES 64 /* upper bound on n_surf accepted by every entry point */
 
 /* error codes */
@@ -231,17 +231,32 @@ int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const u
  * wavelength 0, id = ray_id as int8).  The reference draws its uniforms from torch.distributions.Uniform
  * (low + rand * (high - low)); here rand comes from Philox4x32-10 keyed by `seed`: the pair of rays with
  * global indices (2j, 2j+1) uses counter (j lo, j hi, 0, 0) and the outputs (x0, x1 | x2, x3) as its
- * (first, second) uniform, u = (x >> 8) * 2^-24.  A ray's values depend only on (seed, global index), so
- * shards that pass their global `offset` reproduce the single-call bundle. */
+ * (first, second) uniform, u = (x >> 8) * 2^-24.  Sources that draw four uniforms per ray (RTT_SRC_PANEL,
+ * RTT_SRC_SPHERE) use counter (i lo, i hi, 1, 0) of the ray's global index i: (x0, x1) are the two position
+ * draws, (x2, x3) the two direction draws.  A ray's values depend only on (seed, global index), so shards
+ * that pass their global `offset` reproduce the single-call bundle. */
 enum {
   RTT_SRC_PENCIL = 0, /* Bundle: pos 0, dir +z                                 rays/bundle.py:24-28   */
   RTT_SRC_DISK = 1,   /* DiskSample: theta = U(par[2], par[3]) first, then r = sqrt(U(par[0], par[1]));
                          pos (r cos, r sin, 0), dir +z                         rays/bundle.py:40-56,83-98 */
   RTT_SRC_LINE = 2,   /* pos (U(par[0], par[1]), 0, 0), dir +z                 rays/bundle.py:101-118 */
   RTT_SRC_FAN = 3,    /* theta = U(par[0], par[1]); dir (0, sin, cos)          rays/bundle.py:121-140 */
-  RTT_SRC_POINT = 4   /* phi = acos(1 - 2 U(par[0], par[1])) first, then theta = U(par[2], par[3]);
+  RTT_SRC_POINT = 4,  /* phi = acos(1 - 2 U(par[0], par[1])) first, then theta = U(par[2], par[3]);
                          dir (cos(theta) sin(phi), sin(theta) sin(phi), cos(phi)) rays/bundle.py:58-80,143-171 */
+  RTT_SRC_GAUSS = 5,  /* GaussianBeam: pos (par[0] z0, par[1] z1, 0), z0 and z1 independent standard normals
+                         (Box-Muller of the two uniforms: sqrt(-2 ln(1-ua)) (cos, sin)(2 pi ub)), dir +z.
+                         The reference draws torch.normal values: same distribution, other stream.  rays/beam.py:9-41 */
+  RTT_SRC_RAYLEIGH = 6, /* cos(theta) = A - 1/A, A = cbrt(sqrt(q^2+1) - q), q = 2 - 4 ua; phi = 2 pi ub;
+                         dir (sin cos(phi), sin sin(phi), cos)                 rays/particle.py:90-125 */
+  RTT_SRC_PANEL = 7,  /* PanelSource: position by `area_kind` from par (RTT_AREA_RECT: x = U(par[0], par[1]) first,
+                         then y = U(par[2], par[3]); RTT_AREA_RING: as RTT_SRC_DISK), direction by `emit_kind`
+                         from epar (RTT_EMIT_LAMBERT: (sqrt(u1) cos(2 pi u2), sqrt(u1) sin(2 pi u2), sqrt(1-u1));
+                         RTT_EMIT_CONE: as RTT_SRC_POINT with epar for par)      rays/panels.py:10-154 */
+  RTT_SRC_SPHERE = 8  /* LambertianSphere of radius par[0]: outward normal n from cos_t = 2 u1 - 1, phi = 2 pi u2,
+                         pos = par[0] n; cosine-weighted direction about n in the Frisvad basis rays/particle.py:9-87 */
 };
+enum { RTT_AREA_RECT = 0, RTT_AREA_RING = 1 };
+enum { RTT_EMIT_LAMBERT = 0, RTT_EMIT_CONE = 1 };
 
 typedef struct RttSource {
   int32_t kind, ray_id;
@@ -249,6 +264,8 @@ typedef struct RttSource {
   float R[9], t[3]; /* RayTransformBundle: rotation matrix (row-major) and translation */
   uint64_t seed;    /* Philox key */
   uint64_t offset;  /* global index of the first ray of this call */
+  int32_t area_kind, emit_kind; /* RTT_SRC_PANEL only */
+  float epar[4];                /* RTT_SRC_PANEL with RTT_EMIT_CONE */
 } RttSource;
 
 /* pos, dir: plane triples with leading dimension ld; inten, id, wavelength: [n], each nullable. */

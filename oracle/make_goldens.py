@@ -213,19 +213,29 @@ def gen_grad_tilt(ns):
 
 
 def gen_bundles(ns):
-    """Bundle.sample of the reference, together with the torch.rand values it consumed: Uniform.sample((N,))
-    on [1]-shaped bounds draws torch.rand((N, 1)) once per distribution, in the order the code samples."""
+    """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
+    samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
+    Gaussian beam consumes torch.normal values instead: its golden keeps the standard normals z = x / sigma."""
     n = 4096
-    for name, (mk, kind, par_of, draws) in scenes.bundle_cases(ns).items():
+    for name, case in scenes.bundle_cases(ns).items():
+        mk, kind, par_of, draws = case[:4]
+        panel = case[4] if len(case) > 4 else {}
         b = mk()
         torch.manual_seed(0)
         rays = b.sample(n)
         torch.manual_seed(0)
-        us = [torch.rand((n, 1)).reshape(-1) for _ in range(draws)] + [torch.zeros(n)] * (2 - draws)
+        us = [torch.rand((n, 1)).reshape(-1) for _ in range(draws)] + [torch.zeros(n)] * (4 - draws)
         out = rays_arrays(rays, "")
+        if name == "gauss":
+            torch.manual_seed(0)
+            local = b.sample_pos(n)
+            sx, sy = par_of(b)
+            us[0], us[1] = local[:, 0] / sx, local[:, 1] / sy   # standard normals, not uniforms
         out.update(kind=np.int32(kind), par=np.asarray(par_of(b), dtype=np.float64), ua=npy(us[0]), ub=npy(us[1]),
-                   R=npy(b.transform.rot), t=npy(b.transform.trans), wavelength=npy(rays.wavelength),
-                   ray_id=np.int32(b.ray_id))
+                   uc=npy(us[2]), ud=npy(us[3]), R=npy(b.transform.rot), t=npy(b.transform.trans),
+                   wavelength=npy(rays.wavelength), ray_id=np.int32(b.ray_id),
+                   area=np.int32(panel.get("area", 0)), emit=np.int32(panel.get("emit", 0)),
+                   epar=np.asarray(panel.get("epar", ()), dtype=np.float64))
         np.savez_compressed(os.path.join(OUT, f"bundle_{name}.npz"), **out)
         print("bundle", name, tuple(rays.pos.shape))
 

@@ -88,6 +88,13 @@ def load():
     for n in ("Bundle", "DiskSample", "SolidAngleSample", "CollimatedDisk", "CollimatedLine", "Fan",
               "PointSource"):
         setattr(rays, n, getattr(bun, n))
+    for mod, names in (("panels", ("EmissionModel", "LambertianEmission", "SolidAngleEmission", "PanelSource",
+                                   "RectangularPanel", "RingSource")),
+                       ("beam", ("GaussianBeam",)),
+                       ("particle", ("LambertianSphere", "RayleighScatter", "MieScatter"))):
+        m = importlib.import_module("RayTraceTorch.rays." + mod)
+        for n in names:
+            setattr(rays, n, getattr(m, n))
     top.phys = importlib.import_module("RayTraceTorch.phys")
     top.elements = importlib.import_module("RayTraceTorch.elements")
     top.scene = importlib.import_module("RayTraceTorch.scene")

@@ -16,6 +16,8 @@ kernels or with the host packer: the record layout and the enum values are resta
 
 All citations are file:line relative to the reference tree.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -472,15 +474,17 @@ def spot_size_loss(x, y, w, target_xy=None):
 # reference (fed with the very torch.rand values it consumed) and then drive the check of the device
 # sampler (fed with the Philox values the kernel uses).
 # ------------------------------------------------------------------------------------------------
-SRC_PENCIL, SRC_DISK, SRC_LINE, SRC_FAN, SRC_POINT = range(5)
+SRC_PENCIL, SRC_DISK, SRC_LINE, SRC_FAN, SRC_POINT, SRC_GAUSS, SRC_RAYLEIGH, SRC_PANEL, SRC_SPHERE = range(9)
+AREA_RECT, AREA_RING = 0, 1
+EMIT_LAMBERT, EMIT_CONE = 0, 1
 
 
-def philox4x32_10(counter, key):
-    """Philox4x32-10 (Salmon et al., SC'11; Random123): counter [M] uint64 placed in words 0-1, words 2-3
-    zero; key uint64.  Returns [M, 4] uint32."""
+def philox4x32_10(counter, key, word2=0):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123): counter [M] uint64 placed in words 0-1, word 2 =
+    `word2`, word 3 zero; key uint64.  Returns [M, 4] uint32."""
     counter = np.asarray(counter, dtype=np.uint64)
     m32 = np.uint64(0xFFFFFFFF)
-    c = [counter & m32, counter >> np.uint64(32), np.zeros_like(counter), np.zeros_like(counter)]
+    c = [counter & m32, counter >> np.uint64(32), np.full_like(counter, word2), np.zeros_like(counter)]
     k0, k1 = np.uint64(int(key) & 0xFFFFFFFF), np.uint64((int(key) >> 32) & 0xFFFFFFFF)
     M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
     for _ in range(10):
@@ -502,10 +506,33 @@ def philox_uniforms(seed, offset, n):
     return to_u(blocks[rows, 2 * half]), to_u(blocks[rows, 2 * half + 1])
 
 
-def sample_bundle(kind, par, R, t, ua, ub, dtype=torch.float32):
+def _local_only(kind, par, ua, ub, dtype):
+    return sample_bundle(kind, par, np.eye(3), np.zeros(3), ua, ub, dtype=dtype, local=True)
+
+
+def philox_uniforms4(seed, offset, n):
+    """The four unit uniforms of rays offset .. offset+n-1 of a source that draws four per ray: block
+    (index lo, index hi, 1, 0), words in order."""
+    g = np.arange(offset, offset + n, dtype=np.uint64)
+    blocks = philox4x32_10(g, seed, word2=1)
+    to_u = lambda x: ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    return tuple(to_u(blocks[:, k]) for k in range(4))
+
+
+def _lambert_local(u1, u2):
+    """rays/panels.py:27-37, rays/particle.py:62-68."""
+    r = torch.sqrt(u1)
+    phi = 2.0 * math.pi * u2
+    return torch.stack([r * torch.cos(phi), r * torch.sin(phi), torch.sqrt((1.0 - u1).clamp(min=0.0))], dim=1)
+
+
+def sample_bundle(kind, par, R, t, ua, ub, dtype=torch.float32, uc=None, ud=None, area=AREA_RECT, emit=EMIT_LAMBERT,
+                  epar=(), local=False):
     """Bundle.sample (rays/bundle.py:30-37) as a function of the unit uniforms ua (first draw) and ub
     (second draw): local sample (:40-171), RayTransformBundle.transform_ (geom/transform.py:259-262),
-    F.normalize of Rays.__post_init__ (rays/ray.py:22-25).  Returns (pos [N,3], dir [N,3])."""
+    F.normalize of Rays.__post_init__ (rays/ray.py:22-25).  Sources with a position and a direction sampler
+    (rays/panels.py, rays/particle.py:9-87) take two more, uc and ud, for the direction.  Returns (pos [N,3],
+    dir [N,3]); `local` stops before the bundle pose."""
     ua, ub = _as(ua, dtype).reshape(-1), _as(ub, dtype).reshape(-1)
     par = [torch.tensor(float(v), dtype=dtype) for v in list(par) + [0.0] * (4 - len(par))]
     R = _as(R, dtype).reshape(3, 3)
@@ -529,6 +556,42 @@ def sample_bundle(kind, par, R, t, ua, ub, dtype=torch.float32):
         theta = between(par[2], par[3], ub)
         dr = torch.sin(phi)
         d = torch.stack([torch.cos(theta) * dr, torch.sin(theta) * dr, torch.cos(phi)], dim=1)
+    elif kind == SRC_GAUSS:     # rays/beam.py:37-41; standard normals by Box-Muller of (ua, ub)
+        r = torch.sqrt(-2.0 * torch.log(1.0 - ua))
+        p = torch.stack([par[0] * (r * torch.cos(2.0 * math.pi * ub)), par[1] * (r * torch.sin(2.0 * math.pi * ub)), zero], dim=1)
+    elif kind == SRC_RAYLEIGH:  # rays/particle.py:111-125
+        half_q = 2.0 - 4.0 * ua
+        A = (torch.sqrt(half_q ** 2 + 1.0) - half_q).pow(1.0 / 3.0)
+        ct = A - 1.0 / A
+        st = torch.sqrt((1.0 - ct ** 2).clamp(min=0.0))
+        phi = 2.0 * math.pi * ub
+        d = torch.stack([st * torch.cos(phi), st * torch.sin(phi), ct], dim=1)
+    elif kind == SRC_PANEL:     # rays/panels.py:65-154: position draws first, then the emission model's
+        uc, ud = _as(uc, dtype).reshape(-1), _as(ud, dtype).reshape(-1)
+        if area == AREA_RING:
+            p, _ = _local_only(SRC_DISK, par, ua, ub, dtype)
+        else:
+            p = torch.stack([between(par[0], par[1], ua), between(par[2], par[3], ub), zero], dim=1)
+        if emit == EMIT_CONE:
+            _, d = _local_only(SRC_POINT, epar, uc, ud, dtype)
+        else:
+            d = _lambert_local(uc, ud)
+    elif kind == SRC_SPHERE:    # rays/particle.py:34-87
+        uc, ud = _as(uc, dtype).reshape(-1), _as(ud, dtype).reshape(-1)
+        ct = 2.0 * ua - 1.0
+        st = torch.sqrt((1.0 - ct ** 2).clamp(min=0.0))
+        phi = 2.0 * math.pi * ub
+        nrm = torch.stack([st * torch.cos(phi), st * torch.sin(phi), ct], dim=1)
+        p = nrm * par[0]
+        l = _lambert_local(uc, ud)
+        sign = torch.sign(nrm[:, 2] + 1e-10)
+        a = -1.0 / (sign + nrm[:, 2])
+        b = nrm[:, 0] * nrm[:, 1] * a
+        tg = torch.stack([1.0 + sign * nrm[:, 0] ** 2 * a, sign * b, -sign * nrm[:, 0]], dim=1)
+        bt = torch.stack([b, sign + nrm[:, 1] ** 2 * a, -nrm[:, 1]], dim=1)
+        d = l[:, 0:1] * tg + l[:, 1:2] * bt + l[:, 2:3] * nrm
+    if local:
+        return p, d
     pg = _rowmat_T(p, R) + t[None, :]
     dg = _rowmat_T(d, R)
     return pg, _normalize(dg)

@@ -52,7 +52,8 @@ class RttSource(ctypes.Structure):
     """Mirror of `RttSource` in include/rtt_hip.h (passed by pointer, read on the host)."""
     _fields_ = [("kind", ctypes.c_int32), ("ray_id", ctypes.c_int32), ("par", ctypes.c_float * 4),
                 ("R", ctypes.c_float * 9), ("t", ctypes.c_float * 3), ("seed", ctypes.c_uint64),
-                ("offset", ctypes.c_uint64)]
+                ("offset", ctypes.c_uint64), ("area_kind", ctypes.c_int32), ("emit_kind", ctypes.c_int32),
+                ("epar", ctypes.c_float * 4)]
 
 
 class NativeLibraryError(RuntimeError):

@@ -202,8 +202,8 @@ struct Philox4 {
   uint32_t x[4];
 };
 
-DI Philox4 philox4x32_10(uint64_t counter, uint64_t key) {
-  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+DI Philox4 philox4x32_10(uint64_t counter, uint64_t key, uint32_t word2 = 0u) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = word2, c3 = 0u;
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -1736,6 +1736,8 @@ __global__ void __launch_bounds__(kBlock) k_spot_groups(const float* __restrict_
 // torch.distributions.Uniform.rsample: low + rand * (high - low)
 DI float uniform_between(float lo, float hi, float u) { return lo + u * (hi - lo); }
 
+constexpr float kTwoPi = 6.283185307179586f;
+
 DI void sample_local(const RttSource& src, float ua, float ub, V3<float>& p, V3<float>& d) {
   p = {0.0f, 0.0f, 0.0f};
   d = {0.0f, 0.0f, 1.0f};
@@ -1767,14 +1769,100 @@ DI void sample_local(const RttSource& src, float ua, float ub, V3<float>& p, V3<
       d = {ct * sp, st * sp, cp};
       break;
     }
+    case RTT_SRC_GAUSS: {  // rays/beam.py:37-41 with the normals by Box-Muller
+      const float r = sqrtf(-2.0f * logf(1.0f - ua));
+      float sn, cs;
+      sincosf(kTwoPi * ub, &sn, &cs);
+      p = {src.par[0] * (r * cs), src.par[1] * (r * sn), 0.0f};
+      break;
+    }
+    case RTT_SRC_RAYLEIGH: {  // rays/particle.py:111-125
+      const float q = 2.0f - 4.0f * ua;
+      const float A = powf(sqrtf(q * q + 1.0f) - q, 1.0f / 3.0f);
+      const float ct = A - 1.0f / A;
+      const float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+      float sn, cs;
+      sincosf(kTwoPi * ub, &sn, &cs);
+      d = {st * cs, st * sn, ct};
+      break;
+    }
     default:
       break;
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, float* __restrict__ pos, float* __restrict__ dir,
-                                                          int64_t ld, float* __restrict__ inten, int8_t* __restrict__ id,
-                                                          float* __restrict__ wavelength, int64_t n) {
+// cosine-weighted hemisphere about +z (rays/panels.py:27-37, rays/particle.py:62-68)
+DI V3<float> lambert_local(float u1, float u2) {
+  const float r = sqrtf(u1);
+  float sn, cs;
+  sincosf(kTwoPi * u2, &sn, &cs);
+  return {r * cs, r * sn, sqrtf(fmaxf(1.0f - u1, 0.0f))};
+}
+
+// the sources that draw four uniforms: (ua, ub) place the ray, (uc, ud) aim it
+DI void sample_local_wide(const RttSource& src, float ua, float ub, float uc, float ud, V3<float>& p, V3<float>& d) {
+  if (src.kind == RTT_SRC_SPHERE) {  // rays/particle.py:34-87
+    const float ct = 2.0f * ua - 1.0f;
+    const float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+    float sn, cs;
+    sincosf(kTwoPi * ub, &sn, &cs);
+    const V3<float> n = {st * cs, st * sn, ct};
+    p = scale(src.par[0], n);
+    const V3<float> l = lambert_local(uc, ud);
+    const float v = n.z + 1e-10f;
+    const float sg = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);  // torch.sign
+    const float a = -1.0f / (sg + n.z);
+    const float b = n.x * n.y * a;
+    const V3<float> tg = {1.0f + sg * (n.x * n.x) * a, sg * b, -sg * n.x};
+    const V3<float> bt = {b, sg + (n.y * n.y) * a, -n.y};
+    d = {l.x * tg.x + l.y * bt.x + l.z * n.x, l.x * tg.y + l.y * bt.y + l.z * n.y, l.x * tg.z + l.y * bt.z + l.z * n.z};
+    return;
+  }
+  RttSource part = src;  // RTT_SRC_PANEL: an area sampler and an emission model, each a two-uniform source
+  V3<float> unused;
+  if (src.area_kind == RTT_AREA_RING) {
+    part.kind = RTT_SRC_DISK;
+    sample_local(part, ua, ub, p, unused);
+  } else {  // rays/panels.py:118-122
+    p = {uniform_between(src.par[0], src.par[1], ua), uniform_between(src.par[2], src.par[3], ub), 0.0f};
+  }
+  if (src.emit_kind == RTT_EMIT_CONE) {  // rays/panels.py:40-62
+    part.kind = RTT_SRC_POINT;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part.par[k] = src.epar[k];
+    sample_local(part, uc, ud, unused, d);
+  } else {
+    d = lambert_local(uc, ud);
+  }
+}
+
+struct BundleOut {
+  float* __restrict__ pos;
+  float* __restrict__ dir;
+  int64_t ld;
+  float* __restrict__ inten;
+  int8_t* __restrict__ id;
+  float* __restrict__ wavelength;
+};
+
+DI void store_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V3<float> p, V3<float> d) {
+  // RayTransformBundle.transform_: pos @ R^T + t, dir @ R^T (geom/transform.py:259-262)
+  const float* R = src.R;
+  const V3<float> pg = {p.x * R[0] + p.y * R[1] + p.z * R[2] + src.t[0], p.x * R[3] + p.y * R[4] + p.z * R[5] + src.t[1],
+                        p.x * R[6] + p.y * R[7] + p.z * R[8] + src.t[2]};
+  V3<float> dg = {d.x * R[0] + d.y * R[1] + d.z * R[2], d.x * R[3] + d.y * R[4] + d.z * R[5],
+                  d.x * R[6] + d.y * R[7] + d.z * R[8]};
+  // Rays.__post_init__: F.normalize(dir) = dir / max(|dir|, 1e-12) (rays/ray.py:22-25)
+  const float len = fmaxf(sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z), 1e-12f);
+  dg = {dg.x / len, dg.y / len, dg.z / len};
+  o.pos[i] = pg.x; o.pos[o.ld + i] = pg.y; o.pos[2 * o.ld + i] = pg.z;
+  o.dir[i] = dg.x; o.dir[o.ld + i] = dg.y; o.dir[2 * o.ld + i] = dg.z;
+  if (o.inten) o.inten[i] = 1.0f;
+  if (o.id) o.id[i] = (int8_t)src.ray_id;
+  if (o.wavelength) o.wavelength[i] = 0.0f;
+}
+
+__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, BundleOut o, int64_t n) {
   const uint64_t first_pair = src.offset >> 1;
   const uint64_t pair = first_pair + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const Philox4 rnd = philox4x32_10(pair, src.seed);
@@ -1782,24 +1870,20 @@ __global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, float* 
   for (int h = 0; h < 2; ++h) {
     const uint64_t g = 2 * pair + h;  // global ray index
     if (g < src.offset || g >= src.offset + (uint64_t)n) continue;
-    const int64_t i = (int64_t)(g - src.offset);
     V3<float> p, d;
     sample_local(src, unit_uniform(rnd.x[2 * h]), unit_uniform(rnd.x[2 * h + 1]), p, d);
-    // RayTransformBundle.transform_: pos @ R^T + t, dir @ R^T (geom/transform.py:259-262)
-    const float* R = src.R;
-    const V3<float> pg = {p.x * R[0] + p.y * R[1] + p.z * R[2] + src.t[0], p.x * R[3] + p.y * R[4] + p.z * R[5] + src.t[1],
-                          p.x * R[6] + p.y * R[7] + p.z * R[8] + src.t[2]};
-    V3<float> dg = {d.x * R[0] + d.y * R[1] + d.z * R[2], d.x * R[3] + d.y * R[4] + d.z * R[5],
-                    d.x * R[6] + d.y * R[7] + d.z * R[8]};
-    // Rays.__post_init__: F.normalize(dir) = dir / max(|dir|, 1e-12) (rays/ray.py:22-25)
-    const float len = fmaxf(sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z), 1e-12f);
-    dg = {dg.x / len, dg.y / len, dg.z / len};
-    pos[i] = pg.x; pos[ld + i] = pg.y; pos[2 * ld + i] = pg.z;
-    dir[i] = dg.x; dir[ld + i] = dg.y; dir[2 * ld + i] = dg.z;
-    if (inten) inten[i] = 1.0f;
-    if (id) id[i] = (int8_t)src.ray_id;
-    if (wavelength) wavelength[i] = 0.0f;
+    store_sampled_ray(src, o, (int64_t)(g - src.offset), p, d);
   }
+}
+
+// four uniforms per ray: one Philox block each
+__global__ void __launch_bounds__(kBlock) k_sample_bundle_wide(RttSource src, BundleOut o, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const Philox4 rnd = philox4x32_10(src.offset + (uint64_t)i, src.seed, 1u);
+  V3<float> p, d;
+  sample_local_wide(src, unit_uniform(rnd.x[0]), unit_uniform(rnd.x[1]), unit_uniform(rnd.x[2]), unit_uniform(rnd.x[3]), p, d);
+  store_sampled_ray(src, o, i, p, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2307,13 +2391,22 @@ int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t 
                           float* wavelength, int64_t n, void* stream) {
   if (!src || !pos || !dir) return RTT_E_NULL;
   if (n < 0 || ld < n) return RTT_E_SIZE;
-  if (src->kind < RTT_SRC_PENCIL || src->kind > RTT_SRC_POINT) return RTT_E_KIND;
+  if (src->kind < RTT_SRC_PENCIL || src->kind > RTT_SRC_SPHERE) return RTT_E_KIND;
+  if (src->kind == RTT_SRC_PANEL && (src->area_kind < RTT_AREA_RECT || src->area_kind > RTT_AREA_RING ||
+                                     src->emit_kind < RTT_EMIT_LAMBERT || src->emit_kind > RTT_EMIT_CONE))
+    return RTT_E_KIND;
   if (misaligned(pos) || misaligned(dir) || misaligned(inten) || misaligned(wavelength)) return RTT_E_ALIGN;
   if (n == 0) return RTT_OK;
+  const BundleOut o{pos, dir, ld, inten, id, wavelength};
+  if (src->kind == RTT_SRC_PANEL || src->kind == RTT_SRC_SPHERE) {
+    hipLaunchKernelGGL(k_sample_bundle_wide, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       *src, o, n);
+    return launch_status();
+  }
   const uint64_t first_pair = src->offset >> 1, last_pair = (src->offset + (uint64_t)n - 1) >> 1;
   const uint64_t pairs = last_pair - first_pair + 1;
   hipLaunchKernelGGL(k_sample_bundle, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                     *src, pos, dir, ld, inten, id, wavelength, n);
+                     *src, o, n);
   return launch_status();
 }
 

@@ -240,7 +240,8 @@ def spot_moments(x, y, w, mask, pass_id: int, cx: float, cy: float, wsum: float,
 SRC_PENCIL, SRC_DISK, SRC_LINE, SRC_FAN, SRC_POINT = range(5)
 
 
-def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: int, n: int, device) -> Rays:
+def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: int, n: int, device,
+                  area_kind: int = 0, emit_kind: int = 0, emit_par=()) -> Rays:
     """Bundle.sample(N) on the device: local sample, bundle pose, normalisation, ids (one write-only kernel).
     `rot` is the 3x3 local->global rotation, `trans` the translation; rays get the Philox values of the
     global indices offset .. offset+n-1."""
@@ -252,6 +253,8 @@ def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: in
     src.kind, src.ray_id = int(kind), int(ray_id)
     par = [float(v) for v in par] + [0.0] * (4 - len(par))
     src.par = (ctypes.c_float * 4)(*par)
+    src.area_kind, src.emit_kind = int(area_kind), int(emit_kind)
+    src.epar = (ctypes.c_float * 4)(*([float(v) for v in emit_par] + [0.0] * (4 - len(emit_par))))
     src.R = (ctypes.c_float * 9)(*[float(v) for v in torch.as_tensor(rot, dtype=torch.float32).reshape(-1).tolist()])
     src.t = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(trans, dtype=torch.float32).reshape(-1).tolist()])
     src.seed, src.offset = int(seed) & (2 ** 64 - 1), int(offset)

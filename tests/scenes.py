@@ -284,7 +284,8 @@ def random_system_extra(ns, rng):
 # ray-source cases (rays/bundle.py)
 # ---------------------------------------------------------------------------------------------
 def bundle_cases(ns):
-    """name -> (constructor, device-sampler kind, parameters, number of uniform draws per ray)."""
+    """name -> (constructor, device-sampler kind, parameters, number of uniform draws per ray[, panel description:
+    dict(area=, emit=, epar=)])."""
     import math
     pose = lambda: ns.RayTransformBundle(rotation=[0.1, -0.2, 0.05], translation=[1.0, -2.0, -30.0])
     return {
@@ -297,6 +298,15 @@ def bundle_cases(ns):
         "fan": (lambda: ns.Fan(angle=0.6, ray_id=4, transform=pose()), 3, lambda b: (-0.3, 0.3), 1),
         "point": (lambda: ns.PointSource(NA=0.25, ray_id=5, transform=pose()), 4,
                   lambda b: (0.0, float(b.F_phi_max), 0.0, 2 * math.pi), 2),
+        # normals instead of uniforms: the golden keeps the reference's standard-normal draws
+        "gauss": (lambda: ns.GaussianBeam(2.0, 1.2, ray_id=6, transform=pose()), 5, lambda b: (0.5, 0.3), 2),
+        "rayleigh": (lambda: ns.RayleighScatter(ray_id=7, transform=pose()), 6, lambda b: (), 2),
+        "panel_rect": (lambda: ns.RectangularPanel(3.0, 1.0, ray_id=8, transform=pose()), 7,
+                       lambda b: (-1.5, 1.5, -0.5, 0.5), 4, dict(area=0, emit=0, epar=())),
+        "panel_ring_cone": (lambda: ns.RingSource(1.0, 2.0, ray_id=9, transform=pose(), emission=ns.SolidAngleEmission(0.4)),
+                            7, lambda b: (1.0, 4.0, 0.0, 2 * math.pi), 4,
+                            dict(area=1, emit=1, epar=(0.0, (1 - math.cos(0.4)) / math.pi, 0.0, 2 * math.pi))),
+        "sphere": (lambda: ns.LambertianSphere(2.0, ray_id=10, transform=pose()), 8, lambda b: (2.0,), 4),
     }
 
 
