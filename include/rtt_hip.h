@@ -196,6 +196,20 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
                              int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
                              int64_t hit_capacity, void* stream);
 
+/* Scene.simulate carrying derivatives (the reference gets them from torch autograd through scene/base.py:129-235;
+ * optim/goals.py:63-96 relies on that): the bounce loop above where every ray is a dual number over n_theta (2, 4,
+ * 6 or 8) parameter directions given by the tangent table tan_dev [n_surf][32][n_theta] (layout as for
+ * rtt_trace_seq_tangent_f32).  The winning surface of a bounce is chosen on the values (piecewise constant in the
+ * parameters).  ray_tan [6][n_theta][ld_out] receives d(pos x, y, z, dir x, y, z)/d(theta_k) of the final rays,
+ * hit_tan [hit_capacity][3][n_theta] the tangents of hit_local for the entry of the same index in hit_list.
+ * prog_host is required.  hit_count must be zeroed by the caller; a count above hit_capacity means the list was
+ * truncated and the call must be repeated with more room. */
+int rtt_simulate_nearest_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                                     float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
+                                     const float* tan_dev, int n_theta, float* ray_tan, float* hit_list, int32_t* hit_keys,
+                                     float* hit_tan, int32_t* hit_count, int64_t hit_capacity, void* stream);
+
 /* ---- Element.intersectTest (elements/parent.py:30-42; geom/shape.py:25-59; primitives.py:38-57)
  * t_out[s*ld_t + i] = distance to surface s of the program, inf on a miss. */
 int rtt_intersect_test_f32(const float* pos, const float* dir, int64_t ld, int64_t n,

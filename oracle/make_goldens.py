@@ -212,6 +212,43 @@ def gen_grad_tilt(ns):
     np.savez_compressed(os.path.join(OUT, "grad_tilt.npz"), **out)
 
 
+def gen_grad_naive(ns):
+    """Gradients through Scene.simulate (nearest-hit bounce loop, scene/base.py:129-235) by the reference's autograd,
+    float32 and float64: a folded system in which every ray bounces seven times and crosses the sensor twice.
+    Objective: fixed random projections of the final rays and of all sensor hit positions (in the order of
+    getHitsTensors: bounce by bounce, rays in order)."""
+    torch.manual_seed(5)
+    n = 1024
+    rays = scenes.folded_bundle(ns).sample(n)
+    wp, wd = torch.randn(n, 3), torch.randn(n, 3)
+    out = rays_arrays(rays, "in_")
+    for dtype, dt in ((torch.float32, "f32"), (torch.float64, "f64")):
+        parts = scenes.folded_system(ns)
+        scene = ns.Scene()
+        for el in parts:
+            if dtype == torch.float64:
+                el.double()
+            scene.add_element(el)
+        scene._build_index_maps()
+        scene.rays = ns.Rays.initialize(rays.pos.to(dtype), rays.dir.to(dtype), dtype=dtype)
+        scene.Nbounces = 12
+        scene.simulate()
+        locs, w, _ = parts[2].getHitsTensors()
+        if dt == "f32":
+            torch.manual_seed(6)
+            ws = torch.randn(locs.shape[0], 3)
+            out.update(wp=npy(wp), wd=npy(wd), ws=npy(ws), n_hits=np.int64(locs.shape[0]), hit_locs=npy(locs))
+        r = scene.rays
+        obj = (r.pos * wp.to(dtype)).sum() + (r.dir * wd.to(dtype)).sum() + (locs * ws.to(dtype) * w[:, None]).sum()
+        obj.backward()
+        got = scenes.folded_gradients(*parts)
+        out.update({f"{dt}_{k}": npy(v) for k, v in got.items()})
+        out[f"{dt}_obj"] = npy(obj.detach())
+        out.update(rays_arrays(r, f"{dt}_out_") if dt == "f32" else {})
+        print("grad_naive", dt, float(obj.detach()), locs.shape, {k: np.round(npy(v), 3).tolist() for k, v in got.items()})
+    np.savez_compressed(os.path.join(OUT, "grad_naive.npz"), **out)
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -339,6 +376,8 @@ def main():
     ns = scenes.namespace_from_package(ref)
     if sys.argv[1:] == ["bundles"]:
         return gen_bundles(ns)
+    if sys.argv[1:] == ["naive_grad"]:
+        return gen_grad_naive(ns)
     if sys.argv[1:] == ["tilt"]:
         return gen_grad_tilt(ns)
     if sys.argv[1:] == ["physics"]:
@@ -360,6 +399,7 @@ def main():
     gen_spot(ns, torch.float64, "f64")
     gen_grad_kats(ns)
     gen_grad_tilt(ns)
+    gen_grad_naive(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

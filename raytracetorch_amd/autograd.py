@@ -207,6 +207,72 @@ def trace_sequential_with_grad(elements, rays, prog, group=None):
     return TraceSeqFn.apply(rays, prog, table, thetas, group, *params)
 
 
+class SimulateNearestFn(torch.autograd.Function):
+    """Scene.simulate (nearest-hit bounce loop) as a differentiable function of the scene parameters.
+
+    forward(rays_in, prog, table, thetas, max_bounces, capacity, *params) -> (pos planes, dir planes, intensity,
+    hit [M,4], keys [M,2]); pos, dir and the first three columns of hit carry gradient.  The forward launch
+    carries the tangents along (forward mode, up to 8 directions per launch) and keeps them: d(final rays) as
+    [6, K, N] and d(hit_local) as [M, 3, K]; the backward is their contraction with the upstream adjoints."""
+
+    @staticmethod
+    def forward(ctx, rays_in, prog, table, thetas, max_bounces, capacity, *params):
+        dev = rays_in.device
+        dp = _tangent_program(prog, table, dev)
+        chunks = list(_chunks(table))
+        if len(chunks) > 1:
+            # every launch must take the same branches: one kernel instantiation for all of them
+            chunks = [(k0, used, np.concatenate([pad, np.zeros(pad.shape[:2] + (8 - pad.shape[2],), np.float32)], axis=2))
+                      for k0, used, pad in chunks]
+        kept, first = [], None
+        for k0, used, padded in chunks:
+            out = K.simulate_nearest_tangent(rays_in, dp, max_bounces, padded, capacity)
+            if first is None:
+                first = out
+            elif not torch.equal(out[4], first[4]):
+                raise RuntimeError("sensor hit lists of two tangent launches differ")
+            kept.append((k0, used, out[5], out[6]))
+        pos, dir_, inten, hit, keys = first[:5]
+        ctx.kept, ctx.thetas, ctx.n_theta = kept, thetas, table.shape[2]
+        ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
+        ctx.param_ids = [id(p) for p in params]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(inten, keys)
+        return pos, dir_, inten, hit, keys
+
+    @staticmethod
+    def backward(ctx, g_pos, g_dir, _gi, g_hit, _gk):
+        dev = ctx.kept[0][2].device
+        dtheta = torch.zeros(ctx.n_theta, dtype=torch.float64, device=dev)
+        for k0, used, ray_tan, hit_tan in ctx.kept:
+            acc = torch.zeros(ray_tan.shape[1], dtype=torch.float64, device=dev)
+            if g_pos is not None:
+                acc += torch.einsum("ci,cki->k", g_pos.to(torch.float32), ray_tan[:3]).double()
+            if g_dir is not None:
+                acc += torch.einsum("ci,cki->k", g_dir.to(torch.float32), ray_tan[3:]).double()
+            if g_hit is not None and hit_tan.shape[0]:
+                acc += torch.einsum("mc,mck->k", g_hit[:, :3].to(torch.float32), hit_tan).double()
+            dtheta[k0:k0 + used] = acc[:used]
+        grads = [torch.zeros(shape, dtype=torch.float64, device=dev) for shape, _, _ in ctx.param_meta]
+        where = {pid: k for k, pid in enumerate(ctx.param_ids)}
+        for k, (p, i) in enumerate(ctx.thetas):
+            grads[where[id(p)]].view(-1)[i] = dtheta[k]
+        grads = [g.to(device=d_, dtype=dt) for g, (_, dt, d_) in zip(grads, ctx.param_meta)]
+        return (None,) * 6 + tuple(grads)
+
+
+def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None):
+    """Run the differentiable nearest-hit bounce loop; returns the five outputs of SimulateNearestFn."""
+    thetas = trainable_scalars(elements)
+    table = tangent_table(elements, thetas)
+    params, seen = [], set()
+    for p, _ in thetas:
+        if id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    return SimulateNearestFn.apply(rays, prog, table, thetas, max_bounces, capacity, *params)
+
+
 class SpotLossFn(torch.autograd.Function):
     """sum_i sqrt(((x_i-cx)^2 + (y_i-cy)^2) w_i / W) over entries with mask and w > 0
     (optim/goals.py:165-183), W and the centroid summed over all ranks of `group` when given.

@@ -1479,6 +1479,99 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
   }
 }
 
+// Scene.simulate with tangents: the bounce loop of k_simulate_nearest, one ray per lane, where every ray is a
+// dual number over K parameter directions.  The surface a ray goes to is decided by the nearest-hit search on the
+// values alone (piecewise constant in the parameters, as under autograd: torch.min routes the gradient to the
+// winning column); the visit of that surface is then the dual-number visit of the sequential tangent kernel.
+// Outputs: final rays, d(pos, dir)/d(theta_k) as planes [6][K][ld_out], and per sensor hit the hit_local tangents
+// [3][K] next to the appended hit record.  Intensity multipliers are 0/1 switches and carry no tangent.
+struct NearestTangentIO {
+  const float* tan;  // [n_surf][kTanSlots][K]
+  float* ray_tan;    // [6][K][ld_out]
+  float* hit_tan;    // [cap][3][K]
+};
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_simulate_nearest_tangent(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                                     Ops ops, Cull cull, int max_bounces, SensorIO se,
+                                                                     NearestTangentIO tio) {
+  using T = Dual<K>;
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t rounds = (io.n + stride - 1) / stride;
+  for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    const int64_t want = rnd * stride + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = want < io.n;
+    const int64_t i = live ? want : 0;
+    const Ray<float> r0 = load_ray<float>(io, i);
+    Ray<T> r;
+    r.p = {T(r0.p.x), T(r0.p.y), T(r0.p.z)};
+    r.d = {T(r0.d.x), T(r0.d.y), T(r0.d.z)};
+    r.I = T(r0.I);
+    bool open = live;
+    for (int b = 0; b < max_bounces; ++b) {
+      const bool act = open && r.I.v > 0.0f;
+      if (!__any(act)) break;
+      float tmin;
+      int win;
+      nearest<float>(prog, n_surf, ops, V3<float>{r.p.x.v, r.p.y.v, r.p.z.v}, V3<float>{r.d.x.v, r.d.y.v, r.d.z.v}, tmin, win, cull,
+                     0, &act);
+      if (act && win < 0) open = false;
+      bool pending = act && win >= 0;
+      while (pending) {  // one surface per pass, its record and tangent rows addressed from scalar registers
+        const int s = __builtin_amdgcn_readfirstlane(win);
+        if (win == s) {
+          pending = false;
+          const RecD<K> S{prog[s], tio.tan + (int64_t)s * kTanSlots * K};
+          Frames<T> f;
+          T t_raw;
+          // the dual solve repeats the intersection; should its filters disagree with the search on a borderline
+          // root, the ray counts as a miss
+          if (!test_surface<CGeneric>(S, r.p, r.d, f, t_raw)) {
+            open = false;
+            continue;
+          }
+          const Forward<T> fw = surface_forward<CGeneric>(S, r.p, r.d, f, t_raw);
+          V3<T> nd;
+          T im;
+          apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)i);
+          if (S.r.flags & RTT_F_SENSOR) {
+            const int at = atomicAdd(se.app_count, 1);
+            if (at < se.app_cap) {
+              float* h = se.app_hit + 4 * (int64_t)at;
+              h[0] = fw.hit_l.x.v;
+              h[1] = fw.hit_l.y.v;
+              h[2] = fw.hit_l.z.v;
+              h[3] = r.I.v;
+              se.app_key[2 * (int64_t)at] = b * RTT_MAX_SURFACES + S.r.sensor_slot;
+              se.app_key[2 * (int64_t)at + 1] = (int32_t)i;
+              float* ht = tio.hit_tan + (int64_t)at * 3 * K;
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                ht[k] = fw.hit_l.x.tan(k);
+                ht[K + k] = fw.hit_l.y.tan(k);
+                ht[2 * K + k] = fw.hit_l.z.tan(k);
+              }
+            }
+          }
+          r.p = fw.hit_g;
+          r.d = nd;
+          r.I = T(r.I.v * im.v);
+        }
+      }
+    }
+    if (!live) continue;
+    const Ray<float> out = {{r.p.x.v, r.p.y.v, r.p.z.v}, {r.d.x.v, r.d.y.v, r.d.z.v}, r.I.v};
+    store_ray<float>(io, i, out);
+    const T comps[6] = {r.p.x, r.p.y, r.p.z, r.d.x, r.d.y, r.d.z};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) tio.ray_tan[((int64_t)c * K + k) * io.ld_out + i] = comps[c].tan(k);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Renderer.render_3d (render/camera.py:191-257, :259-318): nearest hit over the surfaces that take part,
 // the winner's global normal (Shape.forward / Surface.forward), colour = base colour of the surface times
@@ -2356,6 +2449,45 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
   hipLaunchKernelGGL((k_simulate_nearest<f2, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
                      n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces,
                      se, vec);
+  return launch_status();
+}
+
+int rtt_simulate_nearest_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                                     float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
+                                     const float* tan_dev, int n_theta, float* ray_tan, float* hit_list, int32_t* hit_keys,
+                                     float* hit_tan, int32_t* hit_count, int64_t hit_capacity, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host || !tan_dev || !ray_tan)
+    return RTT_E_NULL;
+  if (n < 0 || n > 0x7fffffff || ld_in < n || ld_out < n || max_bounces < 0 || hit_capacity < 0 ||
+      hit_capacity > 0x7fffffff || n_theta < 2 || n_theta > 8 || (n_theta & 1))
+    return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out) || misaligned(tan_dev) || misaligned(ray_tan) || misaligned(hit_list) || misaligned(hit_keys) ||
+      misaligned(hit_tan) || misaligned(hit_count))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (any_sensor && (!hit_count || (hit_capacity > 0 && (!hit_list || !hit_keys || !hit_tan)))) return RTT_E_NULL;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+  SensorIO se = {};
+  se.app_hit = hit_list;
+  se.app_key = hit_keys;
+  se.app_count = hit_count;
+  se.app_cap = (int32_t)hit_capacity;
+  const NearestTangentIO tio = {tan_dev, ray_tan, hit_tan};
+  const dim3 grid(grid_for(n, 1)), block(kBlock);
+  const Ops ops = make_ops(prog_host, n_surf);
+  const Cull cull = make_cull(prog_host, n_surf);
+  hipStream_t st = (hipStream_t)stream;
+  switch (n_theta) {
+    case 2: hipLaunchKernelGGL((k_simulate_nearest_tangent<2>), grid, block, 0, st, io, prog_dev, n_surf, ops, cull, max_bounces, se, tio); break;
+    case 4: hipLaunchKernelGGL((k_simulate_nearest_tangent<4>), grid, block, 0, st, io, prog_dev, n_surf, ops, cull, max_bounces, se, tio); break;
+    case 6: hipLaunchKernelGGL((k_simulate_nearest_tangent<6>), grid, block, 0, st, io, prog_dev, n_surf, ops, cull, max_bounces, se, tio); break;
+    default: hipLaunchKernelGGL((k_simulate_nearest_tangent<8>), grid, block, 0, st, io, prog_dev, n_surf, ops, cull, max_bounces, se, tio); break;
+  }
   return launch_status();
 }
 

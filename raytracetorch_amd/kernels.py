@@ -199,6 +199,45 @@ def simulate_nearest(rays: Rays, prog: np.ndarray, max_bounces: int, want_bounce
     return bounces, ((hit, keys) if has_sensor else None)
 
 
+def simulate_nearest_tangent(rays: Rays, dp, max_bounces: int, tangents: np.ndarray, first_capacity: int = None):
+    """Scene.simulate with dual-number rays over the 2, 4, 6 or 8 parameter directions of `tangents`
+    ([n_surf, 32, K] float32), out of place.  Returns (pos [3,N], dir [3,N], intensity [N], hit [M,4], keys [M,2],
+    ray_tan [6,K,N], hit_tan [M,3,K]); the hit list is sorted by (bounce, sensor slot, ray), which makes the row order
+    the same in every call on the same rays and program."""
+    n = _check_rays(rays)
+    dev = rays.device
+    width = int(tangents.shape[2])
+    has_sensor = P.n_sensor_slots(dp.host) > 0
+    out_pos, out_dir, out_int = torch.empty_like(rays._pos), torch.empty_like(rays._dir), torch.empty_like(rays.intensity)
+    ray_tan = torch.zeros((6, width, n), device=dev, dtype=torch.float32)
+    tan_dev = torch.from_numpy(np.ascontiguousarray(tangents, dtype=np.float32)).to(dev)
+    cap = (2 * n if first_capacity is None else int(first_capacity)) if has_sensor else 0
+    while True:
+        hit = torch.empty((cap, 4), device=dev, dtype=torch.float32)
+        keys = torch.empty((cap, 2), device=dev, dtype=torch.int32)
+        hit_tan = torch.empty((cap, 3, width), device=dev, dtype=torch.float32)
+        count = torch.zeros((1,), device=dev, dtype=torch.int32)
+        if n and dp.n and max_bounces > 0:
+            with torch.cuda.device(dev):
+                code = N.lib().rtt_simulate_nearest_tangent_f32(
+                    N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+                    N.ptr(out_pos), N.ptr(out_dir), N.ptr(out_int), n, n,
+                    N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(tan_dev), width, N.ptr(ray_tan),
+                    N.ptr(hit), N.ptr(keys), N.ptr(hit_tan), N.ptr(count), cap, N.stream_handle(dev))
+            N.check(code, "rtt_simulate_nearest_tangent_f32")
+        else:
+            out_pos.copy_(rays._pos); out_dir.copy_(rays._dir); out_int.copy_(rays.intensity)
+        m = int(count.item())
+        if m <= cap:
+            break
+        cap = m     # more sensor crossings than room: trace again
+    hit, keys, hit_tan = hit[:m], keys[:m], hit_tan[:m]
+    if m:
+        order = torch.argsort(keys[:, 0].to(torch.int64) * (n + 1) + keys[:, 1].to(torch.int64))
+        hit, keys, hit_tan = hit[order], keys[order], hit_tan[order]
+    return out_pos, out_dir, out_int, hit, keys, ray_tan, hit_tan
+
+
 def apply_physics(rec: np.ndarray, hit_local, ray_dir, normal):
     """One physics functor on [N,3] tensors -> (new_dir [N,3], imult [N])."""
     N.require_device(hit_local, ray_dir, normal)

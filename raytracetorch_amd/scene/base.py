@@ -124,6 +124,8 @@ class Scene(nn.Module):
         if self.rays is None:
             return
         self._build_index_maps()
+        if self._needs_grad() and not hasattr(self.rays, "_snapshot") and len(self.elements):
+            return self._bounce_with_grad(self.rays, self.Nbounces)
         if hasattr(self.rays, "_snapshot") or len(self.elements) == 0:
             # rays wrapped in Paths want a snapshot per bounce: one launch per bounce, like the reference
             for _ in range(self.Nbounces):
@@ -137,6 +139,21 @@ class Scene(nn.Module):
         _, hits = K.simulate_nearest(self.rays, prog, self.Nbounces, first_capacity=getattr(self, "_hit_capacity", None))
         if hits is not None:
             self._deliver_sensor_hits(prog, self.rays, *hits)
+
+    def _bounce_with_grad(self, rays, max_bounces):
+        """Bounces of `rays` as one differentiable function of the element parameters (the reference records
+        every tensor op of scene/base.py:180-235 on the autograd tape; here the trace carries the tangents)."""
+        from .. import autograd as AG
+        if rays._pos.requires_grad or rays._dir.requires_grad:
+            raise NotImplementedError(
+                "rays that already carry gradients cannot enter a differentiable bounce: run all bounces in one "
+                "simulate() call, or detach the rays")
+        prog = self._program()
+        pos, dir_, inten, hit, keys = AG.simulate_nearest_with_grad(self.elements, rays, prog, max_bounces,
+                                                                    getattr(self, "_hit_capacity", None))
+        rays._pos, rays._dir, rays.intensity = pos, dir_, inten
+        if P.n_sensor_slots(prog) > 0:
+            self._deliver_sensor_hits(prog, rays, hit, keys)
 
     def _deliver_sensor_hits(self, prog, rays, hit, keys):
         """Hand an unsorted hit list to the sensors as the reference's per-bounce list entries: one entry per
@@ -176,8 +193,14 @@ class Scene(nn.Module):
         if self.rays is None or len(self.elements) == 0:
             return
         raw = self.rays.unwrap() if hasattr(self.rays, "unwrap") else self.rays
-        prog = self._program()
         recording = raw is not self.rays and hasattr(self.rays, "_snapshot")   # rays wrapped in Paths
+        if self._needs_grad():
+            before = raw._pos
+            self._bounce_with_grad(raw, 1)
+            if recording and not torch.equal(before, raw._pos.detach()):
+                self.rays._snapshot()
+            return
+        prog = self._program()
         lit = raw.intensity > 0 if recording else None
         winner, sens_hit, sens_w, sens_mask = K.step_nearest(raw, prog, want_winner=recording)
         self._deliver_sensor_records(prog, raw, sens_hit, sens_w, sens_mask)

@@ -100,6 +100,34 @@ def tilt_system(ns, rot):
     return lens, sensor
 
 
+def folded_system(ns):
+    """Nearest-hit scene with several bounces per ray and trainable poses, curvatures and index: a sensor that rays
+    cross twice, a singlet, and a concave mirror that sends the beam back through both.  All coordinates stay below
+    0.5: a ray that starts on a surface finds that surface again at |t| of a few ulp of its position, and the
+    reference's `t <= 1e-6` filter only removes that root while positions are this small (at |z| = 40 a float32
+    trace re-hits the surface it stands on for a third of the rays)."""
+    lens = singlet(ns, c1=5.0, c2=-5.0, d=0.1, t=0.03, c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True,
+                   transform=ns.RayTransform(translation=[0.001, -0.0005, 0.0], rotation=[0.0, 0.0, 0.0], trans_grad=True, rot_grad=True))
+    mirror = ns.SphericalMirror(c1=-2.0, d=0.0, diameter=0.3, c1_grad=True,
+                                transform=ns.RayTransform(translation=[0.0, 0.0, 0.4], rotation=[0.01, -0.02, 0.0],
+                                                          trans_grad=True, rot_grad=True))
+    sensor = ns.Sensor(ns.Disk(0.12, transform=ns.RayTransform(translation=[0.0, 0.0, -0.1], trans_grad=True)))
+    return lens, mirror, sensor
+
+
+def folded_bundle(ns):
+    return ns.CollimatedDisk(radius=0.03, ray_id=0,
+                             transform=ns.RayTransformBundle(translation=[0.0, 0.0, -0.3], rotation=[0.01, -0.01, 0.0]))
+
+
+def folded_gradients(lens, mirror, sensor):
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    return dict(lens_rot=lens.shape.transform.rot_vec.grad, lens_trans=lens.shape.transform.trans.grad,
+                c1=s0.c.grad, c2=s1.c.grad, t1=s1.transform.trans.grad, ior_glass=lens.ior_glass.grad,
+                mirror_c=mirror.shape.c.grad, mirror_rot=mirror.shape.transform.rot_vec.grad,
+                mirror_trans=mirror.shape.transform.trans.grad, sensor_trans=sensor.shape.transform.trans.grad)
+
+
 def tilt_gradients(lens, sensor):
     s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
     return dict(lens_rot=lens.shape.transform.rot_vec.grad, lens_trans=lens.shape.transform.trans.grad,

@@ -193,3 +193,63 @@ def test_pose_gradients_match_reference(ns, tag):
         for a, b, c in zip(v, want, truth):
             # within 1e-4 of the float32 reference, or as close to its float64 gradient as the float32 reference is
             assert abs(a - b) <= GRAD_TOL * scale or abs(a - c) <= 1.5 * abs(b - c) + 1e-6 * scale, (tag, k, a, b, c)
+
+
+def _folded_scene(ns, g):
+    parts = scenes.folded_system(ns)
+    scene = ns.Scene()
+    for el in parts:
+        scene.add_element(el)
+    scene._build_index_maps()
+    scene.rays = ns.Rays.initialize(torch.from_numpy(g["in_pos"]), torch.from_numpy(g["in_dir"])).to(DEV)
+    scene.Nbounces = 12
+    return scene, parts
+
+
+def test_gradients_through_the_nearest_hit_bounce_loop(ns):
+    """Scene.simulate of a folded system (seven bounces per ray, two sensor crossings, 17 trainable scalars: three
+    launches of up to eight directions) against the reference's autograd, float32 and float64."""
+    g = golden("grad_naive")
+    scene, parts = _folded_scene(ns, g)
+    scene.simulate()
+    locs, w, _ = parts[2].getHitsTensors()
+    assert locs.shape[0] == int(g["n_hits"]) and locs.requires_grad
+    assert np.abs(locs.detach().cpu().numpy() - g["hit_locs"]).max() < 1e-5
+    assert np.abs(scene.rays.pos.detach().cpu().numpy() - g["f32_out_pos"]).max() < 1e-5
+    wp, wd, ws = (torch.from_numpy(g[k]).to(DEV) for k in ("wp", "wd", "ws"))
+    r = scene.rays
+    obj = (r.pos * wp).sum() + (r.dir * wd).sum() + (locs * ws * w[:, None]).sum()
+    assert rel(obj, g["f32_obj"]) < 1e-5
+    obj.backward()
+    got = scenes.folded_gradients(*parts)
+    for k, v in got.items():
+        assert v is not None, k
+        v = v.detach().cpu().double().numpy().reshape(-1)
+        want, truth = g[f"f32_{k}"].reshape(-1).astype(np.float64), g[f"f64_{k}"].reshape(-1)
+        scale = max(1.0, np.abs(truth).max())
+        for a, b, c in zip(v, want, truth):
+            assert abs(a - b) <= GRAD_TOL * scale or abs(a - c) <= 1.5 * abs(b - c) + 1e-6 * scale, (k, a, b, c)
+
+
+def test_differentiable_bounces_equal_the_plain_ones(ns):
+    """Values of the differentiable bounce loop against the plain one (other kernel, same formulas), one
+    differentiable step against simulate with one bounce, and the refusal to chain differentiable steps."""
+    g = golden("grad_naive")
+    scene, parts = _folded_scene(ns, g)
+    scene.simulate()
+    with_grad = scene.rays.pos.detach().clone()
+    hits = parts[2].getHitsTensors()[0].detach().clone()
+    plain, parts2 = _folded_scene(ns, g)
+    with torch.no_grad():
+        plain.simulate()
+    assert (with_grad - plain.rays.pos).abs().max() < 1e-5
+    assert (hits - parts2[2].getHitsTensors()[0]).abs().max() < 1e-5
+    one, _ = _folded_scene(ns, g)
+    one.step()
+    assert one.rays._pos.requires_grad
+    single, _ = _folded_scene(ns, g)
+    single.Nbounces = 1
+    single.simulate()
+    assert torch.equal(one.rays._pos, single.rays._pos)
+    with pytest.raises(NotImplementedError):
+        one.step()
