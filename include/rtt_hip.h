@@ -144,6 +144,16 @@ int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const fl
                               const float* tan_dev, int n_theta, const float* adj_pos, const float* adj_dir,
                               int64_t ld_adj, const float* adj_sens, int64_t sens_ld, double* dtheta, void* stream);
 
+/* The same backward w.r.t. the input rays themselves (torch autograd follows rays.pos / rays.dir back to whatever
+ * made them: a trainable bundle pose geom/transform.py:247-264, an earlier trace): the six directions are the
+ * components of each ray's own input, and the contraction with the upstream adjoints is stored per ray instead of
+ * summed: ray_adj[k*ld_ray + i] = d(objective)/d(component k of ray i), k = pos x, y, z, dir x, y, z.
+ * zero_tan_dev: [n_surf][32][6] zeros in device memory (the scene parameters do not move here). */
+int rtt_trace_seq_ray_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                                  const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                                  const float* zero_tan_dev, const float* adj_pos, const float* adj_dir, int64_t ld_adj,
+                                  const float* adj_sens, int64_t sens_ld, float* ray_adj, int64_t ld_ray, void* stream);
+
 /* ---- fused backward of the spot-size loss (optim/goals.py:144-187 followed by .backward()):
  * the same tangent trace, with the loss adjoint formed in the kernel from the primal hit point on sensor
  * slot `sensor_slot`, g = (x-cx, y-cy)(w/W)/sqrt(((x-cx)^2+(y-cy)^2) w/W) for hits with intensity w > 0.
@@ -202,13 +212,17 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
  * rtt_trace_seq_tangent_f32).  The winning surface of a bounce is chosen on the values (piecewise constant in the
  * parameters).  ray_tan [6][n_theta][ld_out] receives d(pos x, y, z, dir x, y, z)/d(theta_k) of the final rays,
  * hit_tan [hit_capacity][3][n_theta] the tangents of hit_local for the entry of the same index in hit_list.
+ * With seed_rays != 0 (n_theta >= 6) directions 0..5 are the components (pos x, y, z, dir x, y, z) of each ray's own
+ * input on top of the table, so that ray_tan[c][j][i] is the Jacobian of ray i: the reference's autograd reaches
+ * the rays' origin (a trainable bundle pose, an earlier step) the same way.
  * prog_host is required.  hit_count must be zeroed by the caller; a count above hit_capacity means the list was
  * truncated and the call must be repeated with more room. */
 int rtt_simulate_nearest_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
                                      float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                                      const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
-                                     const float* tan_dev, int n_theta, float* ray_tan, float* hit_list, int32_t* hit_keys,
-                                     float* hit_tan, int32_t* hit_count, int64_t hit_capacity, void* stream);
+                                     const float* tan_dev, int n_theta, int seed_rays, float* ray_tan, float* hit_list,
+                                     int32_t* hit_keys, float* hit_tan, int32_t* hit_count, int64_t hit_capacity,
+                                     void* stream);
 
 /* ---- Element.intersectTest (elements/parent.py:30-42; geom/shape.py:25-59; primitives.py:38-57)
  * t_out[s*ld_t + i] = distance to surface s of the program, inf on a miss. */

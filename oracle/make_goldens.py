@@ -249,6 +249,56 @@ def gen_grad_naive(ns):
     np.savez_compressed(os.path.join(OUT, "grad_naive.npz"), **out)
 
 
+def gen_grad_rays(ns):
+    """Gradients that reach the rays' origin: a bundle whose pose is trainable feeds (a) the sequential tilt system
+    and (b) the folded nearest-hit system; the reference's autograd gives d(objective)/d(bundle pose) next to the
+    element gradients.  Float32 and float64."""
+    out = {}
+    n = 1024
+    torch.manual_seed(8)
+    wp, wd = torch.randn(n, 3), torch.randn(n, 3)
+    out.update(wp=npy(wp), wd=npy(wd))
+    for case in ("seq", "naive"):
+        for dtype, dt in ((torch.float32, "f32"), (torch.float64, "f64")):
+            bundle = scenes.trainable_bundle(ns, case)
+            torch.manual_seed(9)
+            rays = bundle.sample(n)
+            if dtype == torch.float64:
+                rays = ns.Rays.initialize(rays.pos.double(), rays.dir.double(), dtype=dtype)
+            if case == "seq":
+                parts = scenes.tilt_system(ns, [0.03, -0.02, 0.1])
+                scene = ns.SequentialScene(list(parts))
+            else:
+                parts = scenes.folded_system(ns)
+                scene = ns.Scene()
+                for el in parts:
+                    scene.add_element(el)
+                scene._build_index_maps()
+                scene.Nbounces = 12
+            if dtype == torch.float64:
+                for el in parts:
+                    el.double()
+            if case == "seq":
+                r = scene.simulate(rays)
+            else:
+                scene.rays = rays
+                scene.simulate()
+                r = scene.rays
+            locs, w, _ = parts[-1].getHitsTensors()
+            if dt == "f32":
+                torch.manual_seed(10)
+                ws = torch.randn(locs.shape[0], 3)
+                out[f"{case}_ws"] = npy(ws)
+            obj = (r.pos * wp.to(dtype)).sum() + (r.dir * wd.to(dtype)).sum() + (locs * ws.to(dtype) * w[:, None]).sum()
+            obj.backward()
+            got = dict(bundle_trans=bundle.transform.trans.grad, bundle_rot=bundle.transform.rot_vec.grad,
+                       c1=parts[0].shape.surfaces[0].c.grad, lens_trans=parts[0].shape.transform.trans.grad)
+            out.update({f"{case}_{dt}_{k}": npy(v) for k, v in got.items()})
+            out[f"{case}_{dt}_obj"] = npy(obj.detach())
+            print("grad_rays", case, dt, float(obj.detach()), {k: np.round(npy(v), 3).tolist() for k, v in got.items()})
+    np.savez_compressed(os.path.join(OUT, "grad_rays.npz"), **out)
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -378,6 +428,8 @@ def main():
         return gen_bundles(ns)
     if sys.argv[1:] == ["naive_grad"]:
         return gen_grad_naive(ns)
+    if sys.argv[1:] == ["ray_grad"]:
+        return gen_grad_rays(ns)
     if sys.argv[1:] == ["tilt"]:
         return gen_grad_tilt(ns)
     if sys.argv[1:] == ["physics"]:
@@ -400,6 +452,7 @@ def main():
     gen_grad_kats(ns)
     gen_grad_tilt(ns)
     gen_grad_naive(ns)
+    gen_grad_rays(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

@@ -42,7 +42,9 @@ _SIGNATURES = {
     "rtt_simulate_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                  _vp, _vp, _vp, _vp, _i64, _vp],
     "rtt_simulate_nearest_tangent_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
-                                         _vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+                                         _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "rtt_trace_seq_ray_adjoint_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
+                                      _vp, _i64, _vp],
     "rtt_spot_groups_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _vp, _vp],
     "rtt_render_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp],
     "rtt_sample_bundle_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],

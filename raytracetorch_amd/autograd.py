@@ -154,14 +154,34 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     return out
 
 
-class TraceSeqFn(torch.autograd.Function):
-    """SequentialScene.simulate as a differentiable function of the scene parameters.
+def _ray_adjoint(rays_in, prog, adj_pos, adj_dir, adj_sens):
+    """[6, N]: d(objective)/d(pos x, y, z, dir x, y, z of every input ray) of a sequential trace."""
+    n, dev = len(rays_in), rays_in.device
+    out = torch.zeros((6, n), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    dp = N.DeviceProgram.upload(prog, dev)
+    fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
+    adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
+    zero_tan = torch.zeros((dp.n, TAN_SLOTS, 6), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        code = N.lib().rtt_trace_seq_ray_adjoint_f32(
+            N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+            N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(zero_tan), N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+            N.ptr(out), n, N.stream_handle(dev))
+    N.check(code, "rtt_trace_seq_ray_adjoint_f32")
+    return out
 
-    forward(rays_in, prog, table, thetas, group, *params) -> (pos planes, dir planes, intensity,
-    sens_hit, sens_w, sens_mask); only pos, dir and sens_hit carry gradient."""
+
+class TraceSeqFn(torch.autograd.Function):
+    """SequentialScene.simulate as a differentiable function of the scene parameters and of the input rays.
+
+    forward(rays_in, prog, table, thetas, group, pos_in, dir_in, *params) -> (pos planes, dir planes, intensity,
+    sens_hit, sens_w, sens_mask); only pos, dir and sens_hit carry gradient.  `rays_in` holds detached planes (what
+    the kernels read); `pos_in` / `dir_in` are the same planes as the caller has them, possibly with a graph."""
 
     @staticmethod
-    def forward(ctx, rays_in, prog, table, thetas, group, *params):
+    def forward(ctx, rays_in, prog, table, thetas, group, pos_in, dir_in, *params):
         from .rays.ray import Rays
         # the kernel writes every ray of `out`, so fresh uninitialised planes are enough
         out = Rays.from_planes(torch.empty_like(rays_in._pos), torch.empty_like(rays_in._dir),
@@ -183,20 +203,34 @@ class TraceSeqFn(torch.autograd.Function):
             g_sens = None
         dtheta = _tangent_contract(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens)
         allreduce_sum_(dtheta, ctx.group)
+        g_pos_in = g_dir_in = None
+        if ctx.needs_input_grad[5] or ctx.needs_input_grad[6]:
+            adj = _ray_adjoint(ctx.rays_in, ctx.prog, g_pos, g_dir, g_sens)
+            g_pos_in, g_dir_in = adj[:3], adj[3:]
         grads = [torch.zeros(shape, dtype=torch.float64, device=dtheta.device) for shape, _, _ in ctx.param_meta]
         where = {pid: k for k, pid in enumerate(ctx.param_ids)}
         for k, (p, i) in enumerate(ctx.thetas):
             grads[where[id(p)]].view(-1)[i] = dtheta[k]
         grads = [g.to(device=dev, dtype=dt) for g, (_, dt, dev) in zip(grads, ctx.param_meta)]
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, g_pos_in, g_dir_in, *grads)
 
 
 def needs_grad(elements) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for el in elements for p in el.parameters())
 
 
+def rays_carry_grad(rays) -> bool:
+    return torch.is_grad_enabled() and (rays._pos.requires_grad or rays._dir.requires_grad)
+
+
+def _detached(rays):
+    from .rays.ray import Rays
+    return Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id, rays.wavelength)
+
+
 def trace_sequential_with_grad(elements, rays, prog, group=None):
-    """Run the differentiable trace; returns the six outputs of TraceSeqFn."""
+    """Run the differentiable trace of `rays` (whose planes may carry a graph); returns the six outputs of
+    TraceSeqFn."""
     thetas = trainable_scalars(elements)
     table = tangent_table(elements, thetas)
     params, seen = [], set()
@@ -204,23 +238,27 @@ def trace_sequential_with_grad(elements, rays, prog, group=None):
         if id(p) not in seen:
             seen.add(id(p))
             params.append(p)
-    return TraceSeqFn.apply(rays, prog, table, thetas, group, *params)
+    return TraceSeqFn.apply(_detached(rays), prog, table, thetas, group, rays._pos, rays._dir, *params)
 
 
 class SimulateNearestFn(torch.autograd.Function):
     """Scene.simulate (nearest-hit bounce loop) as a differentiable function of the scene parameters.
 
-    forward(rays_in, prog, table, thetas, max_bounces, capacity, *params) -> (pos planes, dir planes, intensity,
-    hit [M,4], keys [M,2]); pos, dir and the first three columns of hit carry gradient.  The forward launch
-    carries the tangents along (forward mode, up to 8 directions per launch) and keeps them: d(final rays) as
-    [6, K, N] and d(hit_local) as [M, 3, K]; the backward is their contraction with the upstream adjoints."""
+    forward(rays_in, prog, table, thetas, max_bounces, capacity, pos_in, dir_in, *params) -> (pos planes, dir
+    planes, intensity, hit [M,4], keys [M,2]); pos, dir and the first three columns of hit carry gradient.  The
+    forward launch carries the tangents along (forward mode, up to 8 directions per launch) and keeps them: d(final
+    rays) as [6, K, N] and d(hit_local) as [M, 3, K]; the backward is their contraction with the upstream adjoints.
+    When the input planes `pos_in` / `dir_in` carry a graph, one more launch keeps the per-ray Jacobian."""
 
     @staticmethod
-    def forward(ctx, rays_in, prog, table, thetas, max_bounces, capacity, *params):
+    def forward(ctx, rays_in, prog, table, thetas, max_bounces, capacity, pos_in, dir_in, *params):
         dev = rays_in.device
         dp = _tangent_program(prog, table, dev)
         chunks = list(_chunks(table))
-        if len(chunks) > 1:
+        seeds = pos_in.requires_grad or dir_in.requires_grad
+        if not chunks:   # no trainable scalar: one launch for the values
+            chunks = [(0, 0, np.zeros((table.shape[0], TAN_SLOTS, 2), np.float32))]
+        if len(chunks) > 1 or seeds:
             # every launch must take the same branches: one kernel instantiation for all of them
             chunks = [(k0, used, np.concatenate([pad, np.zeros(pad.shape[:2] + (8 - pad.shape[2],), np.float32)], axis=2))
                       for k0, used, pad in chunks]
@@ -233,6 +271,13 @@ class SimulateNearestFn(torch.autograd.Function):
                 raise RuntimeError("sensor hit lists of two tangent launches differ")
             kept.append((k0, used, out[5], out[6]))
         pos, dir_, inten, hit, keys = first[:5]
+        ctx.jac = None
+        if seeds:
+            out = K.simulate_nearest_tangent(rays_in, dp, max_bounces, np.zeros((table.shape[0], TAN_SLOTS, 8), np.float32),
+                                             capacity, seed_rays=True)
+            if not torch.equal(out[4], keys):
+                raise RuntimeError("sensor hit lists of two tangent launches differ")
+            ctx.jac = (out[5][:, :6], out[6][:, :, :6], keys[:, 1].to(torch.int64))
         ctx.kept, ctx.thetas, ctx.n_theta = kept, thetas, table.shape[2]
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
@@ -244,21 +289,36 @@ class SimulateNearestFn(torch.autograd.Function):
     def backward(ctx, g_pos, g_dir, _gi, g_hit, _gk):
         dev = ctx.kept[0][2].device
         dtheta = torch.zeros(ctx.n_theta, dtype=torch.float64, device=dev)
+        f32 = lambda g: None if g is None else g.to(torch.float32)
+        g_pos, g_dir, g_hit = f32(g_pos), f32(g_dir), (None if g_hit is None else f32(g_hit[:, :3]))
         for k0, used, ray_tan, hit_tan in ctx.kept:
+            if used == 0:
+                continue
             acc = torch.zeros(ray_tan.shape[1], dtype=torch.float64, device=dev)
             if g_pos is not None:
-                acc += torch.einsum("ci,cki->k", g_pos.to(torch.float32), ray_tan[:3]).double()
+                acc += torch.einsum("ci,cki->k", g_pos, ray_tan[:3]).double()
             if g_dir is not None:
-                acc += torch.einsum("ci,cki->k", g_dir.to(torch.float32), ray_tan[3:]).double()
+                acc += torch.einsum("ci,cki->k", g_dir, ray_tan[3:]).double()
             if g_hit is not None and hit_tan.shape[0]:
-                acc += torch.einsum("mc,mck->k", g_hit[:, :3].to(torch.float32), hit_tan).double()
+                acc += torch.einsum("mc,mck->k", g_hit, hit_tan).double()
             dtheta[k0:k0 + used] = acc[:used]
+        g_pos_in = g_dir_in = None
+        if ctx.jac is not None:
+            jac, hit_jac, hit_ray = ctx.jac
+            adj = torch.zeros((6, jac.shape[2]), dtype=torch.float32, device=dev)
+            if g_pos is not None:
+                adj += torch.einsum("ci,cji->ji", g_pos, jac[:3])
+            if g_dir is not None:
+                adj += torch.einsum("ci,cji->ji", g_dir, jac[3:])
+            if g_hit is not None and hit_jac.shape[0]:
+                adj.index_add_(1, hit_ray, torch.einsum("mc,mcj->jm", g_hit, hit_jac))
+            g_pos_in, g_dir_in = adj[:3], adj[3:]
         grads = [torch.zeros(shape, dtype=torch.float64, device=dev) for shape, _, _ in ctx.param_meta]
         where = {pid: k for k, pid in enumerate(ctx.param_ids)}
         for k, (p, i) in enumerate(ctx.thetas):
             grads[where[id(p)]].view(-1)[i] = dtheta[k]
         grads = [g.to(device=d_, dtype=dt) for g, (_, dt, d_) in zip(grads, ctx.param_meta)]
-        return (None,) * 6 + tuple(grads)
+        return (None,) * 6 + (g_pos_in, g_dir_in) + tuple(grads)
 
 
 def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None):
@@ -270,7 +330,7 @@ def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None)
         if id(p) not in seen:
             seen.add(id(p))
             params.append(p)
-    return SimulateNearestFn.apply(rays, prog, table, thetas, max_bounces, capacity, *params)
+    return SimulateNearestFn.apply(_detached(rays), prog, table, thetas, max_bounces, capacity, rays._pos, rays._dir, *params)
 
 
 class SpotLossFn(torch.autograd.Function):

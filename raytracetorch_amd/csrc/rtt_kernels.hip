@@ -1099,14 +1099,27 @@ struct TangentIO {
   // primal hit point on sensor slot `spot_slot`:  g = (x - cx, y - cy) (w/W) / sqrt(((x-cx)^2+(y-cy)^2) w/W)
   int spot_slot;
   float cx, cy, inv_w;
+  // per-ray mode (PER_RAY = true, K = 6): the six directions are the components of the ray's own input
+  // (pos x, y, z, dir x, y, z); the contraction is not summed over rays but stored, ray_adj[k][i] =
+  // d(objective)/d(input component k of ray i)
+  float* ray_adj;  // [6][ld_ray]
+  int64_t ld_ray;
 };
 
 // NACC accumulators per lane: K (plain) or 3K + 2 (spot: A_k = sum g.dhit_k, Bx_k = sum (w/W) dx_k,
 // By_k = sum (w/W) dy_k, Gx = sum gx, Gy = sum gy; the host forms dL/dtheta_k = A_k - Gx Bx_k - Gy By_k
 // when the centroid is the reference point, optim/goals.py:176-182).
-template <int K, bool SPOT>
+template <int K>
+DI Dual<K> unit_seed(float v, int k) {
+  Dual<K> d(v);
+  if (k & 1) d.tp[k >> 1].y = 1.0f; else d.tp[k >> 1].x = 1.0f;
+  return d;
+}
+
+template <int K, bool SPOT, bool PER_RAY = false>
 __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
                                                               TangentIO tio) {
+  static_assert(!PER_RAY || (K == 6 && !SPOT), "per-ray mode seeds the six ray components");
   using T = Dual<K>;
   constexpr int NACC = SPOT ? 3 * K + 2 : K;
   __shared__ double part[NACC][kBlock / 64];
@@ -1117,8 +1130,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
     Ray<float> r0 = load_ray<float>(io, i);
     Ray<T> r;
-    r.p = {T(r0.p.x), T(r0.p.y), T(r0.p.z)};
-    r.d = {T(r0.d.x), T(r0.d.y), T(r0.d.z)};
+    if (PER_RAY) {
+      r.p = {unit_seed<K>(r0.p.x, 0), unit_seed<K>(r0.p.y, 1), unit_seed<K>(r0.p.z, 2)};
+      r.d = {unit_seed<K>(r0.d.x, 3), unit_seed<K>(r0.d.y, 4), unit_seed<K>(r0.d.z, 5)};
+    } else {
+      r.p = {T(r0.p.x), T(r0.p.y), T(r0.p.z)};
+      r.d = {T(r0.d.x), T(r0.d.y), T(r0.d.z)};
+    }
     r.I = T(r0.I);
     for (int s = 0; s < n_surf; ++s) {
       const RecD<K> S{prog[s], tio.tan + (int64_t)s * kTanSlots * K};
@@ -1170,7 +1188,15 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
 #pragma unroll
       for (int k = 0; k < K; ++k) acc[k] += ax * r.d.x.tan(k) + ay * r.d.y.tan(k) + az * r.d.z.tan(k);
     }
+    if (PER_RAY) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        tio.ray_adj[k * tio.ld_ray + i] = acc[k];
+        acc[k] = 0.0f;
+      }
+    }
   }
+  if (PER_RAY) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NACC; ++k) {
@@ -1489,6 +1515,7 @@ struct NearestTangentIO {
   const float* tan;  // [n_surf][kTanSlots][K]
   float* ray_tan;    // [6][K][ld_out]
   float* hit_tan;    // [cap][3][K]
+  int seed_rays;     // 1: directions 0..5 are the components of each ray's own input (K >= 6)
 };
 
 template <int K>
@@ -1507,6 +1534,10 @@ __global__ void __launch_bounds__(kBlock) k_simulate_nearest_tangent(RayIO io, c
     Ray<T> r;
     r.p = {T(r0.p.x), T(r0.p.y), T(r0.p.z)};
     r.d = {T(r0.d.x), T(r0.d.y), T(r0.d.z)};
+    if (K >= 6 && tio.seed_rays) {
+      r.p = {unit_seed<K>(r0.p.x, 0), unit_seed<K>(r0.p.y, 1), unit_seed<K>(r0.p.z, 2)};
+      r.d = {unit_seed<K>(r0.d.x, 3), unit_seed<K>(r0.d.y, 4), unit_seed<K>(r0.d.z, 5)};
+    }
     r.I = T(r0.I);
     bool open = live;
     for (int b = 0; b < max_bounces; ++b) {
@@ -2277,8 +2308,30 @@ int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const fl
   if (misaligned(adj_pos) || misaligned(adj_dir) || misaligned(adj_sens)) return RTT_E_ALIGN;
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
-  TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta, -1, 0.0f, 0.0f, 0.0f};
+  TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta, -1, 0.0f, 0.0f, 0.0f, nullptr, 0};
   return launch_tangent<false>(io, prog_dev, n_surf, tio, n_theta, (hipStream_t)stream);
+}
+
+int rtt_trace_seq_ray_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                                  const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                                  const float* zero_tan_dev, const float* adj_pos, const float* adj_dir, int64_t ld_adj,
+                                  const float* adj_sens, int64_t sens_ld, float* ray_adj, int64_t ld_ray, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !prog_dev || !zero_tan_dev || !ray_adj) return RTT_E_NULL;
+  if (n < 0 || ld_in < n || ld_ray < n) return RTT_E_SIZE;
+  if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
+  if (adj_sens && sens_ld < n) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(zero_tan_dev) || misaligned(adj_pos) ||
+      misaligned(adj_dir) || misaligned(adj_sens) || misaligned(ray_adj))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
+  TangentIO tio = {zero_tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, nullptr, -1, 0.0f, 0.0f, 0.0f, ray_adj, ld_ray};
+  hipLaunchKernelGGL((k_trace_seq_tangent<6, false, true>), dim3(grid_for_reduction(n)), dim3(kBlock), 0, (hipStream_t)stream, io,
+                     prog_dev, n_surf, tio);
+  return launch_status();
 }
 
 int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
@@ -2290,7 +2343,7 @@ int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const 
   if (sensor_slot < 0 || sensor_slot >= RTT_MAX_SURFACES || !(wsum > 0.0)) return RTT_E_SIZE;
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
-  TangentIO tio = {tan_dev, nullptr, nullptr, 0, nullptr, 0, out, sensor_slot, (float)cx, (float)cy, (float)(1.0 / wsum)};
+  TangentIO tio = {tan_dev, nullptr, nullptr, 0, nullptr, 0, out, sensor_slot, (float)cx, (float)cy, (float)(1.0 / wsum), nullptr, 0};
   return launch_tangent<true>(io, prog_dev, n_surf, tio, n_theta, (hipStream_t)stream);
 }
 
@@ -2455,12 +2508,13 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
 int rtt_simulate_nearest_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
                                      float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                                      const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
-                                     const float* tan_dev, int n_theta, float* ray_tan, float* hit_list, int32_t* hit_keys,
-                                     float* hit_tan, int32_t* hit_count, int64_t hit_capacity, void* stream) {
+                                     const float* tan_dev, int n_theta, int seed_rays, float* ray_tan, float* hit_list,
+                                     int32_t* hit_keys, float* hit_tan, int32_t* hit_count, int64_t hit_capacity,
+                                     void* stream) {
   if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host || !tan_dev || !ray_tan)
     return RTT_E_NULL;
   if (n < 0 || n > 0x7fffffff || ld_in < n || ld_out < n || max_bounces < 0 || hit_capacity < 0 ||
-      hit_capacity > 0x7fffffff || n_theta < 2 || n_theta > 8 || (n_theta & 1))
+      hit_capacity > 0x7fffffff || n_theta < 2 || n_theta > 8 || (n_theta & 1) || (seed_rays && n_theta < 6))
     return RTT_E_SIZE;
   if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
       misaligned(inten_out) || misaligned(tan_dev) || misaligned(ray_tan) || misaligned(hit_list) || misaligned(hit_keys) ||
@@ -2477,7 +2531,7 @@ int rtt_simulate_nearest_tangent_f32(const float* pos_in, const float* dir_in, c
   se.app_key = hit_keys;
   se.app_count = hit_count;
   se.app_cap = (int32_t)hit_capacity;
-  const NearestTangentIO tio = {tan_dev, ray_tan, hit_tan};
+  const NearestTangentIO tio = {tan_dev, ray_tan, hit_tan, seed_rays ? 1 : 0};
   const dim3 grid(grid_for(n, 1)), block(kBlock);
   const Ops ops = make_ops(prog_host, n_surf);
   const Cull cull = make_cull(prog_host, n_surf);

@@ -199,11 +199,13 @@ def simulate_nearest(rays: Rays, prog: np.ndarray, max_bounces: int, want_bounce
     return bounces, ((hit, keys) if has_sensor else None)
 
 
-def simulate_nearest_tangent(rays: Rays, dp, max_bounces: int, tangents: np.ndarray, first_capacity: int = None):
+def simulate_nearest_tangent(rays: Rays, dp, max_bounces: int, tangents: np.ndarray, first_capacity: int = None,
+                             seed_rays: bool = False):
     """Scene.simulate with dual-number rays over the 2, 4, 6 or 8 parameter directions of `tangents`
     ([n_surf, 32, K] float32), out of place.  Returns (pos [3,N], dir [3,N], intensity [N], hit [M,4], keys [M,2],
     ray_tan [6,K,N], hit_tan [M,3,K]); the hit list is sorted by (bounce, sensor slot, ray), which makes the row order
-    the same in every call on the same rays and program."""
+    the same in every call on the same rays and program.  With `seed_rays` (K >= 6) directions 0..5 are the
+    components of each ray's own input, so ray_tan[:, :6] is the per-ray Jacobian."""
     n = _check_rays(rays)
     dev = rays.device
     width = int(tangents.shape[2])
@@ -222,11 +224,14 @@ def simulate_nearest_tangent(rays: Rays, dp, max_bounces: int, tangents: np.ndar
                 code = N.lib().rtt_simulate_nearest_tangent_f32(
                     N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
                     N.ptr(out_pos), N.ptr(out_dir), N.ptr(out_int), n, n,
-                    N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(tan_dev), width, N.ptr(ray_tan),
+                    N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(tan_dev), width, int(bool(seed_rays)), N.ptr(ray_tan),
                     N.ptr(hit), N.ptr(keys), N.ptr(hit_tan), N.ptr(count), cap, N.stream_handle(dev))
             N.check(code, "rtt_simulate_nearest_tangent_f32")
         else:
             out_pos.copy_(rays._pos); out_dir.copy_(rays._dir); out_int.copy_(rays.intensity)
+            if seed_rays:
+                for c in range(6):
+                    ray_tan[c, c] = 1.0
         m = int(count.item())
         if m <= cap:
             break

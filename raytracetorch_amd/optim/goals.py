@@ -58,8 +58,8 @@ class SpotSizeLoss(Goal):
         from .. import kernels as K
         from .. import program as P
         from ..rays.ray import Rays
-        if not scene._needs_grad():
-            return None
+        if not scene._needs_grad() or rays._pos.requires_grad or rays._dir.requires_grad:
+            return None   # rays with a graph of their own (a trainable bundle pose) take the general path
         prog = scene._program()
         slots = [int(r["sensor_slot"]) for r in prog if int(r["sensor_slot"]) >= 0
                  and scene.elements[int(r["element_id"])] is self.sensor]

@@ -85,8 +85,14 @@ class Scene(nn.Module):
             self._param_list = plist
         return plist
 
-    def _needs_grad(self) -> bool:
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self._element_params()[1])
+    def _needs_grad(self, rays=None) -> bool:
+        """Whether a trace must be differentiable: a trainable element parameter, or (when `rays` is given) input
+        rays that carry a graph themselves (a trainable bundle pose, an earlier differentiable trace)."""
+        if not torch.is_grad_enabled():
+            return False
+        if rays is not None and (rays._pos.requires_grad or rays._dir.requires_grad):
+            return True
+        return any(p.requires_grad for p in self._element_params()[1])
 
     def _program(self):
         """Packed surface program of the current elements; re-packed only when an element list entry or a
@@ -124,7 +130,7 @@ class Scene(nn.Module):
         if self.rays is None:
             return
         self._build_index_maps()
-        if self._needs_grad() and not hasattr(self.rays, "_snapshot") and len(self.elements):
+        if not hasattr(self.rays, "_snapshot") and len(self.elements) and self._needs_grad(self.rays):
             return self._bounce_with_grad(self.rays, self.Nbounces)
         if hasattr(self.rays, "_snapshot") or len(self.elements) == 0:
             # rays wrapped in Paths want a snapshot per bounce: one launch per bounce, like the reference
@@ -144,10 +150,6 @@ class Scene(nn.Module):
         """Bounces of `rays` as one differentiable function of the element parameters (the reference records
         every tensor op of scene/base.py:180-235 on the autograd tape; here the trace carries the tangents)."""
         from .. import autograd as AG
-        if rays._pos.requires_grad or rays._dir.requires_grad:
-            raise NotImplementedError(
-                "rays that already carry gradients cannot enter a differentiable bounce: run all bounces in one "
-                "simulate() call, or detach the rays")
         prog = self._program()
         pos, dir_, inten, hit, keys = AG.simulate_nearest_with_grad(self.elements, rays, prog, max_bounces,
                                                                     getattr(self, "_hit_capacity", None))
@@ -194,8 +196,8 @@ class Scene(nn.Module):
             return
         raw = self.rays.unwrap() if hasattr(self.rays, "unwrap") else self.rays
         recording = raw is not self.rays and hasattr(self.rays, "_snapshot")   # rays wrapped in Paths
-        if self._needs_grad():
-            before = raw._pos
+        if self._needs_grad(raw):
+            before = raw._pos.detach()
             self._bounce_with_grad(raw, 1)
             if recording and not torch.equal(before, raw._pos.detach()):
                 self.rays._snapshot()

@@ -32,14 +32,11 @@ class SequentialScene(Scene):
                 rays._snapshot(hist[s])
             return rays
         from .. import autograd as AG
-        if self._needs_grad():
-            # differentiable w.r.t. the scene parameters: the backward re-traces the input bundle, whose
-            # planes stay untouched because the result goes into new tensors (nothing is written in place)
-            from ..rays.ray import Rays
-            saved = Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id,
-                                     rays.wavelength)
+        if self._needs_grad(rays):
+            # differentiable w.r.t. the scene parameters and the input rays: the backward re-traces the input
+            # bundle, whose planes stay untouched because the result goes into new tensors
             pos, d, inten, sens_hit, sens_w, sens_mask = AG.trace_sequential_with_grad(
-                list(self.elements), saved, prog, group=getattr(self, "grad_group", None))
+                list(self.elements), rays, prog, group=getattr(self, "grad_group", None))
             dst = rays if out is None else out
             dst._pos, dst._dir, dst.intensity = pos, d, inten
             if sens_hit.numel() == 0:

@@ -120,6 +120,15 @@ def folded_bundle(ns):
                              transform=ns.RayTransformBundle(translation=[0.0, 0.0, -0.3], rotation=[0.01, -0.01, 0.0]))
 
 
+def trainable_bundle(ns, case):
+    """A disk source whose pose is trainable, sized for the tilt system ('seq') or the folded system ('naive')."""
+    if case == "seq":
+        return ns.CollimatedDisk(radius=3.5, ray_id=0, transform=ns.RayTransformBundle(
+            translation=[0.1, -0.2, -30.0], rotation=[0.02, 0.01, 0.0], trans_grad=True, rot_grad=True))
+    return ns.CollimatedDisk(radius=0.03, ray_id=0, transform=ns.RayTransformBundle(
+        translation=[0.0, 0.0, -0.3], rotation=[0.01, -0.01, 0.0], trans_grad=True, rot_grad=True))
+
+
 def folded_gradients(lens, mirror, sensor):
     s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
     return dict(lens_rot=lens.shape.transform.rot_vec.grad, lens_trans=lens.shape.transform.trans.grad,

@@ -162,7 +162,7 @@ def test_generic_and_fused_backward_agree(ns):
                 loss = spot_size_from_records([(hit[0], hit[1], w, mask)], target)
             loss.backward()
             s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
-            grads.append((float(loss), [float(s0.c.grad), float(s1.c.grad), float(s0.transform.trans.grad[2]),
+            grads.append((float(loss.detach()), [float(s0.c.grad), float(s1.c.grad), float(s0.transform.trans.grad[2]),
                                         float(s1.transform.trans.grad[2]), float(lens.ior_glass.grad)]))
         assert rel(grads[0][0], grads[1][0]) < 1e-6
         for a, b in zip(grads[0][1], grads[1][1]):
@@ -233,7 +233,7 @@ def test_gradients_through_the_nearest_hit_bounce_loop(ns):
 
 def test_differentiable_bounces_equal_the_plain_ones(ns):
     """Values of the differentiable bounce loop against the plain one (other kernel, same formulas), one
-    differentiable step against simulate with one bounce, and the refusal to chain differentiable steps."""
+    differentiable step against simulate with one bounce."""
     g = golden("grad_naive")
     scene, parts = _folded_scene(ns, g)
     scene.simulate()
@@ -251,5 +251,66 @@ def test_differentiable_bounces_equal_the_plain_ones(ns):
     single.Nbounces = 1
     single.simulate()
     assert torch.equal(one.rays._pos, single.rays._pos)
-    with pytest.raises(NotImplementedError):
-        one.step()
+
+
+@pytest.mark.parametrize("case", ["seq", "naive"])
+def test_gradients_reach_the_bundle_pose(ns, case):
+    """Rays sampled from a bundle with a trainable pose carry a graph; the trace hands the objective's gradient
+    back to them (per-ray input adjoint), next to the element gradients.  Reference autograd, float32 / float64."""
+    g = golden("grad_rays")
+    bundle = scenes.trainable_bundle(ns, case)
+    torch.manual_seed(9)
+    rays = bundle.sample(1024).to(DEV)
+    assert rays._pos.requires_grad
+    if case == "seq":
+        parts = scenes.tilt_system(ns, [0.03, -0.02, 0.1])
+        r = ns.SequentialScene(list(parts)).simulate(rays)
+    else:
+        parts = scenes.folded_system(ns)
+        scene = ns.Scene()
+        for el in parts:
+            scene.add_element(el)
+        scene._build_index_maps()
+        scene.Nbounces = 12
+        scene.rays = rays
+        scene.simulate()
+        r = scene.rays
+    locs, w, _ = parts[-1].getHitsTensors()
+    wp, wd, ws = (torch.from_numpy(g[k]).to(DEV) for k in ("wp", "wd", case + "_ws"))
+    obj = (r.pos * wp).sum() + (r.dir * wd).sum() + (locs * ws * w[:, None]).sum()
+    assert rel(obj, g[f"{case}_f32_obj"]) < 1e-5
+    obj.backward()
+    got = dict(bundle_trans=bundle.transform.trans.grad, bundle_rot=bundle.transform.rot_vec.grad,
+               c1=parts[0].shape.surfaces[0].c.grad, lens_trans=parts[0].shape.transform.trans.grad)
+    for k, v in got.items():
+        assert v is not None, k
+        v = v.detach().cpu().double().numpy().reshape(-1)
+        want, truth = g[f"{case}_f32_{k}"].reshape(-1).astype(np.float64), g[f"{case}_f64_{k}"].reshape(-1)
+        scale = max(1.0, np.abs(truth).max())
+        for a, b, c in zip(v, want, truth):
+            assert abs(a - b) <= GRAD_TOL * scale or abs(a - c) <= 1.5 * abs(b - c) + 1e-6 * scale, (case, k, a, b, c)
+
+
+def test_chained_differentiable_steps_equal_one_simulate(ns):
+    """Three Scene.step() calls, each a differentiable function of the rays the previous one produced, against
+    simulate() with three bounces: same values, same parameter gradients."""
+    g = golden("grad_naive")
+    grads = []
+    for chained in (True, False):
+        scene, parts = _folded_scene(ns, g)
+        if chained:
+            for _ in range(3):
+                scene.step()
+        else:
+            scene.Nbounces = 3
+            scene.simulate()
+        wp = torch.from_numpy(g["wp"]).to(DEV)
+        locs = parts[2].getHitsTensors()[0]
+        ((scene.rays.pos * wp).sum() + locs.sum()).backward()
+        grads.append((scene.rays.pos.detach().clone(), scenes.folded_gradients(*parts)))
+    assert (grads[0][0] - grads[1][0]).abs().max() < 1e-6
+    for k in grads[0][1]:
+        a, b = grads[0][1][k], grads[1][1][k]
+        if a is None and b is None:
+            continue   # the mirror is not reached in three bounces
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-4 * float(b.abs().max()) + 1e-6), (k, a, b)
