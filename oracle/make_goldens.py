@@ -299,6 +299,58 @@ def gen_grad_rays(ns):
     np.savez_compressed(os.path.join(OUT, "grad_rays.npz"), **out)
 
 
+def gen_paraxial(ns):
+    """Paraxial matrices (elements/*.py getParaxial, scene/sequential.py:38-62), FocalLengthLoss with its gradients
+    (optim/goals.py:16-39), and the log-barrier constraints (optim/constraints.py) on a system with every element
+    kind that has a matrix."""
+    els = scenes.paraxial_system(ns)
+    out = {}
+    for i, el in enumerate(els):
+        zs, mats = el.getParaxial()
+        out[f"z_{i}"] = np.array([float(z) for z in zs])
+        out[f"mat_{i}"] = np.stack([npy(m) for m in mats])
+    scene = ns.SequentialScene(els)
+    out["system"] = npy(scene.getParaxial())
+    loss = ns.FocalLengthLoss(75.0)(scene)
+    loss.backward()
+    lens = els[0]
+    out.update(focal_loss=npy(loss), g_c1=npy(lens.shape.surfaces[0].c.grad), g_c2=npy(lens.shape.surfaces[1].c.grad),
+               g_ior=npy(lens.ior_glass.grad), g_focal=npy(els[4].P.grad), g_mirror=npy(els[6].shape.c.grad),
+               g_cyl=npy(els[1].shape.surfaces[0].c.grad))
+    lenses = els[:4]
+    cons = dict(thick=ns.ThicknessConstraint(lenses, 0.5, 5.0, weight=2.0), thick_lb=ns.ThicknessConstraint(els, 0.5),
+                space=ns.SpacingConstraint(els, 1.0, weight=0.5), length=ns.SystemLengthConstraint(els, 100.0),
+                none=ns.ThicknessConstraint(els[4:], 0.5))
+    for p in scene.parameters():
+        p.grad = None
+    total = sum(c() for c in cons.values())
+    total.backward()
+    out.update({"con_" + k: npy(c()) for k, c in cons.items()})
+    out.update(con_g_t=npy(lens.shape.surfaces[1].transform.trans.grad), con_g_trans=npy(lens.shape.transform.trans.grad))
+    np.savez_compressed(os.path.join(OUT, "paraxial.npz"), **out)
+    print("paraxial", out["system"][1, 0], float(loss), {k: float(out["con_" + k]) for k in cons})
+
+
+def gen_spot_target(ns):
+    """SpotTargetLoss (optim/goals.py:42-96) on the folded nearest-hit system: two bundles, two targets; value and
+    gradients by the reference's autograd, float32."""
+    parts = scenes.folded_system(ns)
+    scene = ns.Scene()
+    for el in parts:
+        scene.add_element(el)
+    scene._build_index_maps()
+    scene.Nbounces = 12
+    bundles = [scenes.folded_bundle(ns), scenes.trainable_bundle(ns, "naive")]
+    torch.manual_seed(12)
+    loss = ns.SpotTargetLoss(parts[2], torch.tensor([[0.001, -0.002], [0.0, 0.003]]))(scene, bundles, N_rays=512)
+    loss.backward()
+    out = {k: npy(v) for k, v in scenes.folded_gradients(*parts).items()}
+    out.update(loss=npy(loss.detach()), bundle_trans=npy(bundles[1].transform.trans.grad),
+               bundle_rot=npy(bundles[1].transform.rot_vec.grad))
+    np.savez_compressed(os.path.join(OUT, "spot_target.npz"), **out)
+    print("spot_target", float(loss), {k: np.round(v, 4).tolist() for k, v in out.items()})
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -430,6 +482,10 @@ def main():
         return gen_grad_naive(ns)
     if sys.argv[1:] == ["ray_grad"]:
         return gen_grad_rays(ns)
+    if sys.argv[1:] == ["paraxial"]:
+        return gen_paraxial(ns)
+    if sys.argv[1:] == ["spot_target"]:
+        return gen_spot_target(ns)
     if sys.argv[1:] == ["tilt"]:
         return gen_grad_tilt(ns)
     if sys.argv[1:] == ["physics"]:
@@ -453,6 +509,8 @@ def main():
     gen_grad_tilt(ns)
     gen_grad_naive(ns)
     gen_grad_rays(ns)
+    gen_paraxial(ns)
+    gen_spot_target(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

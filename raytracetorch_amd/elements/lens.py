@@ -27,6 +27,12 @@ def _ior(v, grad):
     return nn.Parameter(torch.as_tensor(v, dtype=torch.float32), requires_grad=grad)
 
 
+def _vertex_chain(el, n, iors):
+    from .ideal import ParaxialRefractMat
+    zs = [el.shape.z + el.shape.surfaces[i].z for i in range(n)]
+    return zs, [el._posed(ParaxialRefractMat(zs[i], zs[i], iors[i], iors[i + 1])) for i in range(n)]
+
+
 class SingletLens(Element):
     """Faces: Snell(in=glass, out=media), Snell(in=media, out=glass); edge: Block when `inked`,
     else Snell(in=glass, out=media) (elements/lens.py:13-58)."""
@@ -86,6 +92,19 @@ class SingletLens(Element):
         return self.shape.T_edge
 
 
+    def _face_matrices(self, cx_of):
+        from .ideal import ParaxialRefractMat
+        s0, s1 = self.shape.surfaces[0], self.shape.surfaces[1]
+        zs = [self.shape.z + s0.z, self.shape.z + s1.z]
+        m1 = ParaxialRefractMat(cx_of(s0.c), s0.c, self.ior_media, self.ior_glass)
+        m2 = ParaxialRefractMat(cx_of(s1.c), s1.c, self.ior_glass, self.ior_media)
+        return zs, [self._posed(m1), self._posed(m2)]
+
+    def getParaxial(self):
+        """Refraction matrices of the two faces at their vertex z (elements/lens.py:129-148)."""
+        return self._face_matrices(lambda c: c)
+
+
 class CylSingletLens(SingletLens):
     """Cylindrical singlet: the singlet's three functors with the edge functor repeated for the
     four side planes (elements/lens.py:185-208)."""
@@ -103,6 +122,10 @@ class CylSingletLens(SingletLens):
         for _ in range(3):
             self.surface_functions.append(self.surface_functions[-1])
         self.Nsurfaces = 6
+
+    def getParaxial(self):
+        """Power in y only (elements/lens.py:210-227)."""
+        return self._face_matrices(lambda c: 0.0 * c)
 
 
 class DoubletLens(Element):
@@ -128,6 +151,11 @@ class DoubletLens(Element):
 
     T1 = property(lambda self: self.shape.T1)
     T2 = property(lambda self: self.shape.T2)
+
+    def getParaxial(self):
+        """One refraction matrix per optical surface at its vertex z.  As in the reference, the value handed to the
+        matrix as curvature is the vertex z of the surface (elements/lens.py:303-322, :410-429)."""
+        return _vertex_chain(self, 3, [self.ior_media, self.ior_glass1, self.ior_glass2, self.ior_media])
 
 
 class TripletLens(Element):
@@ -156,3 +184,9 @@ class TripletLens(Element):
     T1 = property(lambda self: self.shape.T1)
     T2 = property(lambda self: self.shape.T2)
     T3 = property(lambda self: self.shape.T3)
+
+    def getParaxial(self):
+        """One refraction matrix per optical surface at its vertex z.  As in the reference, the value handed to the
+        matrix as curvature is the vertex z of the surface (elements/lens.py:303-322, :410-429)."""
+        return _vertex_chain(self, 4, [self.ior_media, self.ior_glass1, self.ior_glass2, self.ior_glass3, self.ior_media])
+

@@ -32,6 +32,15 @@ class Mirror(Element):
     def f(self):
         return 1.0 / (2.0 * self.shape.c)
 
+    # which of (x, y) the mirror focuses in; the paraxial matrix is that of a sphere of the vertex curvature
+    _paraxial_axes = (1.0, 1.0)
+
+    def _paraxial(self):
+        """elements/mirror.py:45-52, :79-88, :115-123, :155-164."""
+        from .ideal import ParaxialMirrorMat
+        c = self.shape.c
+        return ParaxialMirrorMat(self._paraxial_axes[0] * c, self._paraxial_axes[1] * c)
+
 
 class SphericalMirror(Mirror):
     """Spherical cap clipped to `diameter` (elements/mirror.py:22-31)."""
@@ -52,6 +61,8 @@ class CylindricalMirror(Mirror):
         super().__init__()
         self.shape = HalfCyl(curvature=c1, curvature_grad=c1_grad, transform=transform)
         self._set_d(d, d_grad)
+
+    _paraxial_axes = (0.0, 1.0)
 
 
 class ParabolicMirror(Mirror):
@@ -75,3 +86,13 @@ class ParabolicMirrorXZ(Mirror):
         xz = RayTransform(rotation=[0.0, 0.0, math.pi / 2.0], translation=translation)
         self.shape = QuadricZY(c=c1, k=-1.0, c_grad=c1_grad, transform=xz)
         self._set_d(d, d_grad)
+
+    _paraxial_axes = (1.0, 0.0)
+
+
+class ParabolicMirrorOffAxis(Mirror):
+    """Declared and not implemented in the reference either (elements/mirror.py:167-172)."""
+
+    def __init__(self):
+        super().__init__()
+        raise NotImplementedError

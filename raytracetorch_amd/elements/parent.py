@@ -45,6 +45,20 @@ class Element(nn.Module):
         o = self._forward_full(rays, surf_idx)
         return o["hit_global"], o["new_dir"], o["imult"]
 
+    # ---- paraxial description (host-side 5x5 matrices on (x, u, y, v, 1); no rays involved) -----------
+    def _paraxial(self):
+        t = self.shape.transform.trans
+        return torch.eye(5, device=t.device, dtype=t.dtype)
+
+    def _posed(self, mat):
+        """Matrix of a surface seen from the global axis: undo the element's decentre / tilt, act, redo."""
+        tf = self.shape.transform
+        return tf.paraxial_inv() @ mat @ tf.paraxial()
+
+    def getParaxial(self):
+        """([z of each paraxial surface], [its 5x5 matrix]) (elements/parent.py:60-70)."""
+        return [self.shape.z], [self._posed(self._paraxial())]
+
 
 class ElementCustom(Element):
     """One functor shared by every surface of a given shape (elements/parent.py:73-81)."""

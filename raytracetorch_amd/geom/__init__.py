@@ -1,4 +1,4 @@
-from .transform import RayTransform, Vector3, Bool3, RayTransformBundle
+from .transform import RayTransform, Vector3, Bool3, RayTransformBundle, RayTransformNoisy
 from .primitives import Surface, Sphere, Quadric, Plane, QuadricZY, Cylinder, Cone
 from .bounded import (SurfaceBounded, Rectangle, Disk, Ellipse, HalfSphere, BoundedHalfSphere, HalfCyl,
                       SingleCone)

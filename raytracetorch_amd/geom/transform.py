@@ -78,6 +78,55 @@ class RayTransform(nn.Module):
         return _pos @ Rt + self.trans[None, :], _dir @ Rt
 
 
+def _affine5(column):
+    """5x5 identity whose last column is `column` (geom/transform.py:121-139)."""
+    eye = torch.eye(5, device=column.device, dtype=column.dtype)
+    return torch.cat([eye[:, :4], column.unsqueeze(1)], dim=1)
+
+
+def _paraxial(self):
+    """Decentre and tilt of the element as an affine paraxial matrix acting on (x, u, y, v, 1):
+    subtracts (trans_x, rot_x, trans_y, rot_y) (geom/transform.py:121-129)."""
+    one = torch.ones((), device=self.trans.device, dtype=self.trans.dtype)
+    return _affine5(-torch.stack([self.trans[0], self.rot_vec[0], self.trans[1], self.rot_vec[1], -one]))
+
+
+def _paraxial_inv(self):
+    """geom/transform.py:131-139."""
+    one = torch.ones((), device=self.trans.device, dtype=self.trans.dtype)
+    return _affine5(torch.stack([self.trans[0], self.rot_vec[0], self.trans[1], self.rot_vec[1], one]))
+
+
+RayTransform.paraxial = _paraxial
+RayTransform.paraxial_inv = _paraxial_inv
+
+
+class RayTransformNoisy(RayTransform):
+    """Pose with per-ray normal perturbations (geom/transform.py:141-242).  In the reference every `transform_` of
+    this class raises IndexError (`self.rot_vec[:, 0]` on a 3-vector, geom/transform.py:184) and the constructor
+    rejects a zero standard deviation, so there is no behaviour to reproduce: with all deviations zero this is a
+    plain RayTransform, otherwise packing it into a surface program is refused."""
+
+    def __init__(self, rotation: Vector3 = None, translation: Vector3 = None, dtype: torch.dtype = torch.float32,
+                 std_translation: Vector3 = (0, 0, 0), std_rotation: Vector3 = (0, 0, 0),
+                 trans_grad: bool = False, trans_mask: Bool3 = None, rot_grad: bool = False, rot_mask: Bool3 = None):
+        super().__init__(rotation=rotation, translation=translation, dtype=dtype, trans_grad=trans_grad,
+                         trans_mask=trans_mask, rot_grad=rot_grad, rot_mask=rot_mask)
+        self.trans_scale = nn.Parameter(torch.as_tensor(std_translation, dtype=dtype), requires_grad=False)
+        self.rot_scale = nn.Parameter(torch.as_tensor(std_rotation, dtype=dtype), requires_grad=False)
+        self.is_frozen = False
+
+    @property
+    def noisy(self) -> bool:
+        return bool((self.trans_scale != 0).any() or (self.rot_scale != 0).any())
+
+    def freeze_noise(self, N):
+        self.is_frozen = True
+
+    def unfreeze_noise(self):
+        self.is_frozen = False
+
+
 class RayTransformBundle(RayTransform):
     """Pose of a ray source: `transform_` maps the bundle frame to the global frame
     (geom/transform.py:245-277)."""

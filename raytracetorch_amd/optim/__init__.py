@@ -1,1 +1,2 @@
-from .goals import SpotSizeLoss
+from .goals import Goal, FocalLengthLoss, SpotSizeLoss, SpotTargetLoss
+from .constraints import Constraint, ThicknessConstraint, SpacingConstraint, SystemLengthConstraint

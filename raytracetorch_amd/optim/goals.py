@@ -36,6 +36,58 @@ def spot_size_from_records(records, target_xy=None, group=None):
     return SpotLossFn.apply(x, y, w, m, target_xy, group)
 
 
+class FocalLengthLoss(Goal):
+    """(P_system - 1/f_target)^2 with the system power read off the paraxial matrix, P = -M[1, 0]
+    (optim/goals.py:16-39).  No rays: host-side algebra on the parameters."""
+
+    def __init__(self, f_target: float):
+        super().__init__()
+        self.P_target = nn.Parameter(torch.as_tensor(1.0 / f_target), requires_grad=False)
+
+    def forward(self, scene) -> torch.Tensor:
+        M = scene.getParaxial()
+        return (-M[1, 0] - self.P_target) ** 2
+
+
+class SpotTargetLoss(Goal):
+    """Mean over bundles of the squared distance between the intensity centroid of a bundle's sensor hits and
+    its target (optim/goals.py:42-96).  The scene is simulated with its no-argument `simulate()`, i.e. the
+    nearest-hit bounce loop of `Scene`; gradients come from the differentiable form of that loop."""
+
+    def __init__(self, sensor: Sensor, target_xy: torch.Tensor):
+        super().__init__()
+        self.sensor = sensor
+        target_xy = torch.as_tensor(target_xy, dtype=torch.float32)
+        if target_xy.ndim == 1:
+            target_xy = target_xy.unsqueeze(0)
+        self.register_buffer("target_xy", target_xy)
+
+    def forward(self, scene, bundles: List[Bundle], N_rays: int = 128) -> torch.Tensor:
+        losses = []
+        for i, bundle in enumerate(bundles):
+            self.sensor.reset()
+            rays = bundle.sample(N_rays)
+            dev = next(iter(scene.parameters()), torch.zeros(1)).device
+            if dev.type != "cuda" and torch.cuda.is_available():
+                dev = torch.device("cuda", torch.cuda.current_device())
+            scene.rays = rays.to(dev)
+            scene.simulate()
+            if self.sensor.hitLocs:
+                locs, w, _ = self.sensor.getHitsTensors()
+                xy = locs[:, :2]
+            else:
+                xy, w = scene.rays.pos[:, :2], scene.rays.intensity
+            if len(w) == 0:
+                continue
+            w_sum = w.sum().clamp(min=1e-12)
+            cx, cy = (xy[:, 0] * w).sum() / w_sum, (xy[:, 1] * w).sum() / w_sum
+            t = self.target_xy[min(i, self.target_xy.shape[0] - 1)].to(cx.device)
+            losses.append((cx - t[0]) ** 2 + (cy - t[1]) ** 2)
+        if not losses:
+            return torch.tensor(0.0)
+        return torch.stack(losses).mean()
+
+
 class SpotSizeLoss(Goal):
 
     def __init__(self, sensor: Sensor, bundles: List[Bundle], N_rays: int = 128,

@@ -70,6 +70,10 @@ def new_record() -> np.ndarray:
 def set_transform(rec, which: str, transform):
     """Fill (R, t) of the element ('s') or surface ('j') frame from a RayTransform and set the
     identity-rotation flag when R is bit-exactly the identity."""
+    if getattr(transform, "noisy", False):
+        raise NotImplementedError(
+            "RayTransformNoisy with a non-zero deviation: the reference raises IndexError in every transform of this "
+            "class (geom/transform.py:184), so there is no behaviour to reproduce")
     R = host_value(transform.rot).reshape(9)
     t = host_value(transform.trans).reshape(3)
     rec["R" + which] = R

@@ -47,6 +47,24 @@ class SequentialScene(Scene):
         self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask)
         return rays if out is None else out
 
+    def getParaxial(self):
+        """5x5 paraxial matrix of the whole system: the surface matrices of the elements in order, with free-space
+        matrices over the z gaps between consecutive paraxial surfaces (scene/sequential.py:38-62).  Host-side
+        algebra on the parameters; differentiable through torch as it stands."""
+        import torch
+        from ..elements.ideal import ParaxialDistMat
+        zs, mats = [], []
+        for el in self.elements:
+            z, m = el.getParaxial()
+            zs.extend(z)
+            mats.extend(m)
+        system = mats[0].clone()
+        zs = torch.as_tensor(zs)   # detaches the positions, like the reference
+        gaps = zs[1:] - zs[:-1]
+        for i in range(len(mats) - 1):
+            system = mats[i + 1] @ (ParaxialDistMat(gaps[i]) @ system)
+        return system
+
     def to_base(self):
         """scene/sequential.py:80-105."""
         base = Scene()

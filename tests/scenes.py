@@ -22,6 +22,12 @@ def namespace_from_package(pkg):
     ns.Cylinder = pkg.geom.primitives.Cylinder
     ns.Cone = pkg.geom.primitives.Cone
     ns.SpotSizeLoss = pkg.optim.goals.SpotSizeLoss
+    for k in ("FocalLengthLoss", "SpotTargetLoss"):
+        setattr(ns, k, getattr(pkg.optim.goals, k))
+    for k in ("ThicknessConstraint", "SpacingConstraint", "SystemLengthConstraint"):
+        setattr(ns, k, getattr(pkg.optim.constraints, k))
+    ns.ParabolicMirror, ns.ParabolicMirrorXZ = pkg.elements.mirror.ParabolicMirror, pkg.elements.mirror.ParabolicMirrorXZ
+    ns.CylindricalMirror = pkg.elements.mirror.CylindricalMirror
     for k in ("Camera", "OrbitCamera", "Renderer"):
         setattr(ns, k, getattr(pkg.render, k))
     ns.Paths = pkg.rays.Paths
@@ -118,6 +124,25 @@ def folded_system(ns):
 def folded_bundle(ns):
     return ns.CollimatedDisk(radius=0.03, ray_id=0,
                              transform=ns.RayTransformBundle(translation=[0.0, 0.0, -0.3], rotation=[0.01, -0.01, 0.0]))
+
+
+def paraxial_system(ns):
+    """Elements of every kind that has a paraxial matrix, posed and partly trainable, in axial order."""
+    tf = lambda z, **kw: ns.RayTransform(translation=[0.2, -0.1, z], rotation=[0.01, -0.02, 0.0], **kw)
+    return [
+        ns.SingletLens(c1=0.02, c2=-0.02, d=10.0, t=3.0, ior_glass=1.4, c1_grad=True, c2_grad=True, t_grad=True,
+                       ior_glass_grad=True, transform=tf(0.0, trans_grad=True)),
+        ns.CylSingletLens(c1=0.01, c2=-0.015, height=8.0, width=8.0, t=2.0, ior_glass=1.6, c1_grad=True, transform=tf(10.0)),
+        ns.DoubletLens(c1=0.02, c2=-0.03, c3=-0.01, d=10.0, t1=3.0, t2=1.5, ior_glass1=1.5, ior_glass2=1.7, transform=tf(20.0)),
+        ns.TripletLens(c1=0.02, c2=-0.03, c3=0.01, c4=-0.02, d=10.0, t1=2.0, t2=1.0, t3=2.0, ior_glass1=1.5, ior_glass2=1.6,
+                       ior_glass3=1.7, transform=tf(30.0)),
+        ns.IdealThinLens(focal=40.0, focal_grad=True, diameter=10.0, transform=tf(40.0)),
+        ns.CircularAperture(3.0, transform=tf(45.0)),
+        ns.SphericalMirror(c1=-0.01, d=0.0, diameter=20.0, c1_grad=True, transform=tf(50.0)),
+        ns.CylindricalMirror(c1=-0.01, d=0.0, transform=tf(60.0)),
+        ns.ParabolicMirror(c1=0.005, d=0.0, transform=tf(70.0)),
+        ns.ParabolicMirrorXZ(c1=0.004, d=0.0, transform=tf(80.0)),
+    ]
 
 
 def trainable_bundle(ns, case):

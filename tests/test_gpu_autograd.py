@@ -314,3 +314,26 @@ def test_chained_differentiable_steps_equal_one_simulate(ns):
         if a is None and b is None:
             continue   # the mirror is not reached in three bounces
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-4 * float(b.abs().max()) + 1e-6), (k, a, b)
+
+
+def test_spot_target_loss_matches_reference(ns):
+    """SpotTargetLoss on the folded nearest-hit system, one plain and one trainable bundle (optim/goals.py:42-96):
+    value and every gradient against the reference's autograd."""
+    g = golden("spot_target")
+    parts = scenes.folded_system(ns)
+    scene = ns.Scene()
+    for el in parts:
+        scene.add_element(el)
+    scene._build_index_maps()
+    scene.Nbounces = 12
+    bundles = [scenes.folded_bundle(ns), scenes.trainable_bundle(ns, "naive")]
+    torch.manual_seed(12)
+    loss = ns.SpotTargetLoss(parts[2], torch.tensor([[0.001, -0.002], [0.0, 0.003]]))(scene, bundles, N_rays=512)
+    assert rel(loss, g["loss"]) < 1e-4
+    loss.backward()
+    got = scenes.folded_gradients(*parts)
+    got.update(bundle_trans=bundles[1].transform.trans.grad, bundle_rot=bundles[1].transform.rot_vec.grad)
+    scale = max(float(np.abs(g[k]).max()) for k in got)
+    for k, v in got.items():
+        assert v is not None, k
+        assert np.abs(v.detach().cpu().numpy() - g[k]).max() <= 2e-4 * scale, (k, v, g[k])

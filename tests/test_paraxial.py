@@ -1,0 +1,72 @@
+"""Paraxial matrices, FocalLengthLoss and the layout constraints: host-side algebra on the parameters
+(elements/*.py getParaxial, scene/sequential.py:38-62, optim/goals.py:16-39, optim/constraints.py of the reference),
+checked against goldens computed by the unmodified reference.  No rays and no device are involved."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from util import golden
+
+
+def close(a, b, tol=1e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def test_element_and_system_matrices(ns):
+    g = golden("paraxial")
+    els = scenes.paraxial_system(ns)
+    for i, el in enumerate(els):
+        zs, mats = el.getParaxial()
+        assert close([float(torch.as_tensor(z).detach()) for z in zs], g[f"z_{i}"]), i
+        assert close(np.stack([m.detach().numpy() for m in mats]), g[f"mat_{i}"]), (i, type(el).__name__)
+    scene = ns.SequentialScene(els)
+    assert close(scene.getParaxial().detach().numpy(), g["system"])
+
+
+def test_focal_length_loss_and_gradients(ns):
+    g = golden("paraxial")
+    els = scenes.paraxial_system(ns)
+    loss = ns.FocalLengthLoss(75.0)(ns.SequentialScene(els))
+    assert close(loss.detach(), g["focal_loss"])
+    loss.backward()
+    lens = els[0]
+    got = dict(g_c1=lens.shape.surfaces[0].c.grad, g_c2=lens.shape.surfaces[1].c.grad, g_ior=lens.ior_glass.grad,
+               g_focal=els[4].P.grad, g_mirror=els[6].shape.c.grad, g_cyl=els[1].shape.surfaces[0].c.grad)
+    for k, v in got.items():
+        assert close(v, g[k], 1e-4), k
+
+
+def test_singlet_power_matches_the_thick_lens_formula(ns):
+    lens = ns.SingletLens(c1=1 / 50.0, c2=-1 / 50.0, d=10.0, t=30.0, ior_glass=1.4, ior_media=1.0)
+    M = ns.SequentialScene([lens]).getParaxial()
+    n, c1, c2, t = 1.4, 0.02, -0.02, 30.0
+    power = (n - 1) * (c1 - c2 + (n - 1) * t * c1 * c2 / n)
+    assert abs(float(-M[1, 0]) - power) < 1e-6
+    assert abs(float(lens.Power) - power) < 1e-6
+
+
+def test_constraints(ns):
+    g = golden("paraxial")
+    els = scenes.paraxial_system(ns)
+    lenses, lens = els[:4], els[0]
+    cons = dict(thick=ns.ThicknessConstraint(lenses, 0.5, 5.0, weight=2.0), thick_lb=ns.ThicknessConstraint(els, 0.5),
+                space=ns.SpacingConstraint(els, 1.0, weight=0.5), length=ns.SystemLengthConstraint(els, 100.0),
+                none=ns.ThicknessConstraint(els[4:], 0.5))
+    sum(c() for c in cons.values()).backward()
+    for k, c in cons.items():
+        assert close(c().detach(), g["con_" + k]), k
+    assert close(lens.shape.surfaces[1].transform.trans.grad, g["con_g_t"], 1e-4)
+    assert close(lens.shape.transform.trans.grad, g["con_g_trans"], 1e-4)
+
+
+def test_stubs_of_the_reference_stay_stubs(ns):
+    import raytracetorch_amd as rtt
+    with pytest.raises(NotImplementedError):
+        rtt.elements.ParabolicMirrorOffAxis()
+    noisy = rtt.geom.RayTransformNoisy(translation=[0.0, 0.0, 1.0], std_translation=(0.1, 0.0, 0.0))
+    with pytest.raises(NotImplementedError):
+        rtt.geom.Plane(transform=noisy)._record(0)
+    quiet = rtt.geom.RayTransformNoisy(translation=[0.0, 0.0, 1.0])
+    assert float(rtt.geom.Plane(transform=quiet)._record(0)["tj"][2]) == 1.0
