@@ -49,7 +49,21 @@ def test_random_system_sequential_and_nearest(ns, seed, gen):
             el.reset()
         scene.add_element(el)
     scene.rays = rays.to(DEV)
-    scene.step()
+    with torch.no_grad():
+        scene.step()
+    twin_pos = None
+    if any(p.requires_grad for p in scene.parameters()):
+        # the differentiable bounce (dual-number visit) gives the values of the plain one
+        twin = ns.Scene()
+        for el in els:
+            twin.add_element(el)
+        twin.rays = rays.to(DEV)
+        twin.step()
+        assert twin.rays._pos.requires_grad
+        twin_pos = twin.rays.pos.detach().cpu().numpy()
+        for el in els:
+            if hasattr(el, "reset"):
+                el.reset()
     o = O.step_nearest(prog, p0, d0, I0)
     srt = np.sort(tm_o, axis=1)
     tie = np.isfinite(srt[:, 1]) & (np.abs(srt[:, 1] - srt[:, 0]) <= 1e-4 * np.abs(srt[:, 0]))
@@ -60,3 +74,5 @@ def test_random_system_sequential_and_nearest(ns, seed, gen):
     assert_parity(scene.rays.pos.cpu().numpy()[ok], o["pos"].numpy()[ok], o64s["pos"].numpy()[ok], tol=2e-5,
                   what=f"seed {seed} step pos")
     assert np.array_equal((scene.rays.intensity.cpu().numpy() > 0)[ok], (o["intensity"].numpy() > 0)[ok])
+    if twin_pos is not None:
+        assert_parity(twin_pos[ok], o["pos"].numpy()[ok], o64s["pos"].numpy()[ok], tol=2e-5, what=f"seed {seed} differentiable step pos")
