@@ -337,3 +337,51 @@ def test_spot_target_loss_matches_reference(ns):
     for k, v in got.items():
         assert v is not None, k
         assert np.abs(v.detach().cpu().numpy() - g[k]).max() <= 2e-4 * scale, (k, v, g[k])
+
+
+def test_differentiable_paths_on_degenerate_inputs(ns):
+    """Empty bundles, scenes without a sensor, rays with a graph through elements that have no trainable scalar,
+    and rays that all miss: the differentiable paths return the plain values and well-formed (zero) gradients."""
+    lens = scenes.singlet(ns, c1_grad=True)
+    # empty bundle, sequential and nearest-hit
+    empty = ns.Rays.initialize(torch.zeros(0, 3), torch.zeros(0, 3)).to(DEV)
+    out = ns.SequentialScene([lens]).simulate(empty)
+    assert len(out) == 0
+    sc = ns.Scene(); sc.add_element(lens); sc.rays = ns.Rays.initialize(torch.zeros(0, 3), torch.zeros(0, 3)).to(DEV)
+    sc.simulate()
+    assert len(sc.rays) == 0
+    # no trainable scalar anywhere, but the rays carry a graph: gradient w.r.t. a shift of the whole bundle
+    # (small coordinates, so that the float32 bounce loop does not re-hit the face a ray stands on)
+    fixed = scenes.singlet(ns, c1=5.0, c2=-5.0, d=0.1, t=0.03)
+    shift = torch.zeros(3, device=DEV, requires_grad=True)
+    torch.manual_seed(0)
+    host = scenes.folded_bundle(ns).sample(256)
+    base = host.to(DEV)
+
+    def x_sum(dx):   # float64 oracle on the bundle shifted along x
+        p = host.pos.double().clone()
+        p[:, 0] += dx
+        o = O.trace_sequential(P.compile_elements([fixed]), p, host.dir.double(), host.intensity.double(), dtype=torch.float64)
+        return float(o["pos"][:, 0].sum())
+    want = (x_sum(1e-6) - x_sum(-1e-6)) / 2e-6
+    for naive in (False, True):
+        rays = ns.Rays.from_planes(base._pos + shift[:, None], base._dir.clone(), base.intensity.clone(), base.id, base.wavelength)
+        if naive:
+            sc = ns.Scene(); sc.add_element(fixed); sc.rays = rays; sc.Nbounces = 4
+            sc.simulate()
+            res = sc.rays
+        else:
+            res = ns.SequentialScene([fixed]).simulate(rays)
+        assert res._pos.requires_grad
+        shift.grad = None
+        res.pos[:, 0].sum().backward()
+        g = shift.grad.clone()
+        assert abs(float(g[0]) - want) < 1e-3 * abs(want), (naive, g, want)   # central difference of the float64 oracle
+    # every ray misses: values unchanged, gradients exist and vanish
+    far = scenes.disk_bundle(ns, x=100.0).sample(64).to(DEV)
+    p0 = far.pos.clone()
+    res = ns.SequentialScene([lens]).simulate(far)
+    assert torch.equal(res.pos.detach(), p0)
+    lens.shape.surfaces[0].c.grad = None
+    res.pos.sum().backward()
+    assert float(lens.shape.surfaces[0].c.grad) == 0.0
