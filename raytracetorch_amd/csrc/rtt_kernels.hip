@@ -261,6 +261,7 @@ struct Cfg {
 };
 
 using CGeneric = Cfg<DYN, DYN, DYN, DYN, false, DYN>;
+using CGenericIdent = Cfg<DYN, DYN, DYN, DYN, true, DYN>;
 // spherical / conic lens face of a Spheric stack, unrotated element, Snell refraction
 using CFaceSnell = Cfg<RTT_SURF_QUADRIC, RTT_BND_HALF, RTT_SHP_SPHERIC_FACE, RTT_PHYS_SNELL, true>;
 // cylindrical lens edge of a Spheric stack, inked (Block) or clear (Snell)
@@ -1116,7 +1117,9 @@ DI Dual<K> unit_seed(float v, int k) {
   return d;
 }
 
-template <int K, bool SPOT, bool PER_RAY = false>
+// C is the visit configuration: the generic interpreter, or the same with both rotations known to be the identity
+// for every record (the host checks), which frees the registers of the rotated frames.
+template <int K, bool SPOT, bool PER_RAY = false, class C = CGeneric>
 __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const RttSurface* __restrict__ prog, int n_surf,
                                                               TangentIO tio) {
   static_assert(!PER_RAY || (K == 6 && !SPOT), "per-ray mode seeds the six ray components");
@@ -1142,12 +1145,12 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
       const RecD<K> S{prog[s], tio.tan + (int64_t)s * kTanSlots * K};
       Frames<T> f;
       T t_raw;
-      const bool hit = test_surface<CGeneric>(S, r.p, r.d, f, t_raw);
+      const bool hit = test_surface<C>(S, r.p, r.d, f, t_raw);
       if (!hit) continue;
-      Forward<T> fw = surface_forward<CGeneric>(S, r.p, r.d, f, t_raw);
+      Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
       V3<T> nd;
       T im;
-      apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)i);
+      apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)i);
       if (S.r.flags & RTT_F_SENSOR) {
         if (SPOT) {
           const float w = r.I.v;
@@ -2269,15 +2272,33 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
 
 namespace {
 
-template <bool SPOT>
-int launch_tangent(RayIO io, const RttSurface* prog_dev, int n_surf, const TangentIO& tio, int n_theta, hipStream_t st) {
+// every record has both rotations exactly the identity (and a host copy exists to tell)
+bool all_rotations_identity(const RttSurface* prog_host, int n_surf) {
+  if (!prog_host) return false;
+  const int all_id = RTT_F_SHAPE_ROT_ID | RTT_F_SURF_ROT_ID;
+  for (int s = 0; s < n_surf; ++s)
+    if ((prog_host[s].flags & all_id) != all_id) return false;
+  return true;
+}
+
+template <bool SPOT, class C>
+void launch_tangent_cfg(RayIO io, const RttSurface* prog_dev, int n_surf, const TangentIO& tio, int n_theta, hipStream_t st) {
   const dim3 grid(grid_for_reduction(io.n)), block(kBlock);
   switch (n_theta) {
-    case 2: hipLaunchKernelGGL((k_trace_seq_tangent<2, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-    case 4: hipLaunchKernelGGL((k_trace_seq_tangent<4, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-    case 6: hipLaunchKernelGGL((k_trace_seq_tangent<6, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
-    default: hipLaunchKernelGGL((k_trace_seq_tangent<8, SPOT>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 2: hipLaunchKernelGGL((k_trace_seq_tangent<2, SPOT, false, C>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 4: hipLaunchKernelGGL((k_trace_seq_tangent<4, SPOT, false, C>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    case 6: hipLaunchKernelGGL((k_trace_seq_tangent<6, SPOT, false, C>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
+    default: hipLaunchKernelGGL((k_trace_seq_tangent<8, SPOT, false, C>), grid, block, 0, st, io, prog_dev, n_surf, tio); break;
   }
+}
+
+template <bool SPOT>
+int launch_tangent(RayIO io, const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const TangentIO& tio,
+                   int n_theta, hipStream_t st) {
+  if (all_rotations_identity(prog_host, n_surf))
+    launch_tangent_cfg<SPOT, CGenericIdent>(io, prog_dev, n_surf, tio, n_theta, st);
+  else
+    launch_tangent_cfg<SPOT, CGeneric>(io, prog_dev, n_surf, tio, n_theta, st);
   return launch_status();
 }
 
@@ -2309,7 +2330,7 @@ int rtt_trace_seq_tangent_f32(const float* pos_in, const float* dir_in, const fl
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
   TangentIO tio = {tan_dev, adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, dtheta, -1, 0.0f, 0.0f, 0.0f, nullptr, 0};
-  return launch_tangent<false>(io, prog_dev, n_surf, tio, n_theta, (hipStream_t)stream);
+  return launch_tangent<false>(io, prog_dev, prog_host, n_surf, tio, n_theta, (hipStream_t)stream);
 }
 
 int rtt_trace_seq_ray_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
@@ -2344,7 +2365,7 @@ int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const 
   if (n == 0) return RTT_OK;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
   TangentIO tio = {tan_dev, nullptr, nullptr, 0, nullptr, 0, out, sensor_slot, (float)cx, (float)cy, (float)(1.0 / wsum), nullptr, 0};
-  return launch_tangent<true>(io, prog_dev, n_surf, tio, n_theta, (hipStream_t)stream);
+  return launch_tangent<true>(io, prog_dev, prog_host, n_surf, tio, n_theta, (hipStream_t)stream);
 }
 
 int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, const RttSurface* prog_dev,
