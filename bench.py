@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
     ap.add_argument("--tune-lds", type=int, default=-1, help="1: surface program staged in LDS (experiment)")
     ap.add_argument("--tune-blocks", type=int, default=0, help="override the grid cap for experiments")
+    ap.add_argument("--tune-reduce-blocks", type=int, default=0, help="override the grid of the reducing kernels (experiment)")
     ap.add_argument("--tune-cull", type=int, default=-1, help="0: nearest-hit kernels test every surface (experiment)")
     return ap.parse_args()
 
@@ -266,6 +267,8 @@ def main():
         _native.check(_native.lib().rtt_tune(2, a.tune_lds), "rtt_tune")
     if a.tune_blocks:
         _native.check(_native.lib().rtt_tune(1, a.tune_blocks), "rtt_tune")
+    if a.tune_reduce_blocks:
+        _native.check(_native.lib().rtt_tune(5, a.tune_reduce_blocks), "rtt_tune")
     if a.tune_cull >= 0:
         _native.check(_native.lib().rtt_tune(3, a.tune_cull), "rtt_tune")
 

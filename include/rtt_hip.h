@@ -312,7 +312,10 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride);
  * key 2: 1 stages the surface program in LDS, 0 (default) reads it with scalar loads;
  * key 3: 0 makes the nearest-hit kernels test every surface for every ray, 1 (default) lets them skip elements
- * whose bounding sphere lies beyond the nearest hit found so far (same results).
+ * whose bounding sphere lies beyond the nearest hit found so far (same results);
+ * key 4: number of blocks of rtt_spot_moments_f32 (default 768: every block ends in float64 atomics on the same
+ * few addresses, which serialise at about 12 ns each, so more blocks cost more than they stream);
+ * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 
