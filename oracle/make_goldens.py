@@ -351,6 +351,40 @@ def gen_spot_target(ns):
     print("spot_target", float(loss), {k: np.round(v, 4).tolist() for k, v in out.items()})
 
 
+def gen_fuzzy(ns):
+    """Fuzzy filter (phys/filter.py:36-50) in a sequential trace and in three nearest-hit steps: final rays and what
+    the two sensors recorded."""
+    torch.manual_seed(14)
+    rays = scenes.disk_bundle(ns, radius=4.5, rot=[0.01, 0.02, 0.0]).sample(2048)
+    out = rays_arrays(rays, "in_")
+    with torch.no_grad():
+        els = scenes.fuzzy_system(ns)
+        r = ns.SequentialScene(els).simulate(clone_rays(ns, rays))
+        out.update(rays_arrays(r, "seq_"))
+        for k, s in ((0, els[0]), (1, els[3])):
+            locs, w, _ = s.getHitsTensors()
+            out[f"seq_s{k}_locs"], out[f"seq_s{k}_w"] = npy(locs), npy(w)
+        els = scenes.fuzzy_system(ns, small=True)
+        scene = ns.Scene()
+        for el in els:
+            scene.add_element(el)
+        scene._build_index_maps()
+        torch.manual_seed(15)
+        small = ns.CollimatedDisk(radius=0.045, ray_id=0, transform=ns.RayTransformBundle(
+            translation=[0.0, 0.0, -0.3], rotation=[0.01, 0.02, 0.0])).sample(2048)
+        out.update(rays_arrays(small, "small_"))
+        scene.rays = clone_rays(ns, small)
+        for _ in range(5):   # sensor, lens front, lens back, apodiser, sensor
+            scene.step()
+        out.update(rays_arrays(scene.rays, "step5_"))
+        for k, s in ((0, els[0]), (1, els[3])):
+            locs, w, _ = s.getHitsTensors()
+            out[f"step_s{k}_locs"], out[f"step_s{k}_w"] = npy(locs), npy(w)
+    np.savez_compressed(os.path.join(OUT, "fuzzy.npz"), **out)
+    print("fuzzy", out["seq_intensity"].min(), out["seq_intensity"].max(), (out["seq_intensity"] == 0).sum(),
+          out["seq_s1_w"].shape, out["step5_intensity"].mean(), out["step_s1_w"].shape, (out["step5_intensity"] == 0).sum())
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -486,6 +520,8 @@ def main():
         return gen_paraxial(ns)
     if sys.argv[1:] == ["spot_target"]:
         return gen_spot_target(ns)
+    if sys.argv[1:] == ["fuzzy"]:
+        return gen_fuzzy(ns)
     if sys.argv[1:] == ["tilt"]:
         return gen_grad_tilt(ns)
     if sys.argv[1:] == ["physics"]:
@@ -511,6 +547,7 @@ def main():
     gen_grad_rays(ns)
     gen_paraxial(ns)
     gen_spot_target(ns)
+    gen_fuzzy(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

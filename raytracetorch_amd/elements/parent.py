@@ -43,6 +43,9 @@ class Element(nn.Module):
 
     def forward(self, rays, surf_idx):
         o = self._forward_full(rays, surf_idx)
+        fn = self.surface_functions[surf_idx]
+        if hasattr(fn, "block_function"):   # Fuzzy: the multiplier is a host-side function of the local hit point
+            return o["hit_global"], o["new_dir"], o["imult"] * fn.block_function(o["hit_local"])
         return o["hit_global"], o["new_dir"], o["imult"]
 
     # ---- paraxial description (host-side 5x5 matrices on (x, u, y, v, 1); no rays involved) -----------

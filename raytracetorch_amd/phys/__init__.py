@@ -1,2 +1,2 @@
 from .std import SurfaceFunction, Reflect, RefractSnell, RefractFresnel, Linear, Transmit, Block
-from .filter import ApertureFilter
+from .filter import ApertureFilter, Fuzzy

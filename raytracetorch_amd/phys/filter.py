@@ -37,3 +37,25 @@ class ApertureFilter(Transmit):
             owner._fill_bounds(rec)
         elif int(probe["bound_kind"]) != int(rec["bound_kind"]) or not (probe["bnd"] == rec["bnd"]).all():
             raise NotImplementedError("ApertureFilter bound differs from the bound of the surface it sits on")
+
+
+class Fuzzy(Transmit):
+    """Transmit with an intensity multiplier given by a user function of the local hit point
+    (phys/filter.py:36-50).  A Python callable cannot run inside a kernel; geometry does not depend on it, so the
+    kernels treat the surface as a Transmit whose local hit points are recorded (like a sensor's), and the scene
+    applies `intensity_function(hit_local)` to the rays that hit it afterwards: to the final intensities and to the
+    intensity every later sensor recorded (sequential scenes), or after each bounce (nearest-hit scenes, which
+    then run one launch per bounce).  No gradients flow through the function."""
+    _phys_kind = P.PHYS_TRANSMIT
+
+    def __init__(self, intensity_function: Callable):
+        super().__init__()
+        self.block_function = intensity_function
+
+    def _fill_physics(self, rec):
+        rec["phys_kind"] = self._phys_kind
+        rec["flags"] |= P.F_SENSOR   # have the kernels record hit_local for the host-side function
+
+    def forward(self, local_intersect, ray_dir, normal, **kwargs):
+        out_dir, _ = super().forward(local_intersect, ray_dir, normal)
+        return out_dir, self.block_function(local_intersect)

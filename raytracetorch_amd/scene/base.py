@@ -114,13 +114,42 @@ class Scene(nn.Module):
             prog["seed"][stochastic] = (key & 0xFFFFFFFF, key >> 32)
         return prog
 
-    def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask):
-        if sens_hit is None:
-            return
+    def _fuzzy_slots(self, prog):
+        """{sensor slot: intensity function} of the records whose functor is a Fuzzy filter."""
+        out = {}
         for rec in prog:
             k = int(rec["sensor_slot"])
             if k >= 0:
+                fn = self.elements[int(rec["element_id"])].surface_functions[int(rec["surface_id"])]
+                if hasattr(fn, "block_function"):
+                    out[k] = fn.block_function
+        return out
+
+    def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask, dst=None):
+        """Hand the dense records of a trace to the sensors.  Slots are numbered in program order; a Fuzzy
+        filter's slot is not a sensor's: its function of the recorded local hit points multiplies the intensity of
+        the rays that hit it, i.e. the final intensities and what every later slot recorded as incoming intensity
+        (phys/filter.py:36-50 inside scene/sequential.py:12-36)."""
+        if sens_hit is None:
+            return
+        fuzzy = self._fuzzy_slots(prog)
+        factor = None
+        for rec in prog:
+            k = int(rec["sensor_slot"])
+            if k < 0:
+                continue
+            if factor is not None:
+                sens_w[k] *= factor
+            if k in fuzzy:
+                with torch.no_grad():
+                    f = fuzzy[k](sens_hit[k].t()).to(sens_w.dtype).reshape(-1)
+                    f = torch.where(sens_mask[k].bool(), f, torch.ones_like(f))
+                factor = f if factor is None else factor * f
+            else:
                 self.elements[int(rec["element_id"])]._record_dense(sens_hit[k], sens_w[k], sens_mask[k], rays.id)
+        if factor is not None:
+            dst = rays if dst is None else dst   # the rays that hold the result of the trace
+            dst.intensity = dst.intensity * factor
 
     # ---- simulation -------------------------------------------------------------------------------
     def simulate(self):
@@ -132,8 +161,9 @@ class Scene(nn.Module):
         self._build_index_maps()
         if not hasattr(self.rays, "_snapshot") and len(self.elements) and self._needs_grad(self.rays):
             return self._bounce_with_grad(self.rays, self.Nbounces)
-        if hasattr(self.rays, "_snapshot") or len(self.elements) == 0:
-            # rays wrapped in Paths want a snapshot per bounce: one launch per bounce, like the reference
+        if hasattr(self.rays, "_snapshot") or len(self.elements) == 0 or self._has_fuzzy():
+            # rays wrapped in Paths want a snapshot per bounce, and a Fuzzy filter changes intensities (which decide
+            # whether a ray bounces on) between bounces: one launch per bounce, like the reference
             for _ in range(self.Nbounces):
                 if not (self.rays.intensity > 0).any():
                     break
@@ -146,10 +176,16 @@ class Scene(nn.Module):
         if hits is not None:
             self._deliver_sensor_hits(prog, self.rays, *hits)
 
+    def _has_fuzzy(self) -> bool:
+        return any(hasattr(fn, "block_function") for el in self.elements for fn in el.surface_functions)
+
     def _bounce_with_grad(self, rays, max_bounces):
         """Bounces of `rays` as one differentiable function of the element parameters (the reference records
         every tensor op of scene/base.py:180-235 on the autograd tape; here the trace carries the tangents)."""
         from .. import autograd as AG
+        if self._has_fuzzy():
+            raise NotImplementedError("a Fuzzy filter in a differentiable trace: its function runs on the host and "
+                                      "carries no gradient; trace under torch.no_grad()")
         prog = self._program()
         pos, dir_, inten, hit, keys = AG.simulate_nearest_with_grad(self.elements, rays, prog, max_bounces,
                                                                     getattr(self, "_hit_capacity", None))

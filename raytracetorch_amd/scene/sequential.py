@@ -32,6 +32,9 @@ class SequentialScene(Scene):
                 rays._snapshot(hist[s])
             return rays
         from .. import autograd as AG
+        if self._needs_grad(rays) and self._has_fuzzy():
+            raise NotImplementedError("a Fuzzy filter in a differentiable trace: its function runs on the host and "
+                                      "carries no gradient; trace under torch.no_grad()")
         if self._needs_grad(rays):
             # differentiable w.r.t. the scene parameters and the input rays: the backward re-traces the input
             # bundle, whose planes stay untouched because the result goes into new tensors
@@ -44,7 +47,7 @@ class SequentialScene(Scene):
             self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask)
             return dst
         sens_hit, sens_w, sens_mask = K.trace_sequential(rays, prog, out=out)
-        self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask)
+        self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask, dst=out)
         return rays if out is None else out
 
     def getParaxial(self):

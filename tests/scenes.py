@@ -32,6 +32,7 @@ def namespace_from_package(pkg):
         setattr(ns, k, getattr(pkg.render, k))
     ns.Paths = pkg.rays.Paths
     ns.ElementCustom = pkg.elements.parent.ElementCustom
+    ns.Fuzzy = pkg.phys.filter.Fuzzy
     ns.IdealMirror = pkg.elements.ideal.IdealMirror
     ns.IdealCylThinLens = pkg.elements.ideal.IdealCylThinLens
     return ns
@@ -124,6 +125,26 @@ def folded_system(ns):
 def folded_bundle(ns):
     return ns.CollimatedDisk(radius=0.03, ray_id=0,
                              transform=ns.RayTransformBundle(translation=[0.0, 0.0, -0.3], rotation=[0.01, -0.01, 0.0]))
+
+
+def soft_edge(hit_local, unit=1.0):
+    """Intensity profile of the Fuzzy filter in the goldens: a Gaussian apodisation that is exactly zero far out."""
+    r2 = (hit_local[:, 0] ** 2 + hit_local[:, 1] ** 2) / (unit * unit)
+    return torch.exp(-r2 / 4.0) * (r2 < 9.0).to(hit_local.dtype)
+
+
+def soft_edge_small(hit_local):
+    return soft_edge(hit_local, unit=0.01)
+
+
+def fuzzy_system(ns, small=False):
+    """Sensor, singlet, Fuzzy apodiser on a disk, sensor: the second sensor sees apodised intensities.  `small`
+    is the same system at 1/100 scale, where a float32 bounce loop does not re-hit the surface a ray stands on."""
+    u = 0.01 if small else 1.0
+    lens = singlet(ns, c1=5.0, c2=-5.0, d=0.1, t=0.03) if small else singlet(ns)
+    return [ns.Sensor(ns.Disk(8.0 * u, transform=T(ns, -5.0 * u))), lens,
+            ns.ElementCustom(ns.Disk(6.0 * u, transform=T(ns, 8.0 * u)), ns.Fuzzy(soft_edge_small if small else soft_edge), "cpu"),
+            ns.Sensor(ns.Disk(6.0 * u, transform=T(ns, 19.0 * u)))]
 
 
 def paraxial_system(ns):
