@@ -244,18 +244,19 @@ def trace_sequential_with_grad(elements, rays, prog, group=None):
 class SimulateNearestFn(torch.autograd.Function):
     """Scene.simulate (nearest-hit bounce loop) as a differentiable function of the scene parameters.
 
-    forward(rays_in, prog, table, thetas, max_bounces, capacity, pos_in, dir_in, *params) -> (pos planes, dir
+    forward(rays_in, prog, table, thetas, max_bounces, capacity, group, pos_in, dir_in, *params) -> (pos planes, dir
     planes, intensity, hit [M,4], keys [M,2]); pos, dir and the first three columns of hit carry gradient.  The
     forward launch carries the tangents along (forward mode, up to 8 directions per launch) and keeps them: d(final
     rays) as [6, K, N] and d(hit_local) as [M, 3, K]; the backward is their contraction with the upstream adjoints.
     When the input planes `pos_in` / `dir_in` carry a graph, one more launch keeps the per-ray Jacobian."""
 
     @staticmethod
-    def forward(ctx, rays_in, prog, table, thetas, max_bounces, capacity, pos_in, dir_in, *params):
+    def forward(ctx, rays_in, prog, table, thetas, max_bounces, capacity, group, pos_in, dir_in, *params):
         dev = rays_in.device
+        ctx.group = group
         dp = _tangent_program(prog, table, dev)
         chunks = list(_chunks(table))
-        seeds = pos_in.requires_grad or dir_in.requires_grad
+        seeds = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
         if not chunks:   # no trainable scalar: one launch for the values
             chunks = [(0, 0, np.zeros((table.shape[0], TAN_SLOTS, 2), np.float32))]
         if len(chunks) > 1 or seeds:
@@ -302,6 +303,7 @@ class SimulateNearestFn(torch.autograd.Function):
             if g_hit is not None and hit_tan.shape[0]:
                 acc += torch.einsum("mc,mck->k", g_hit, hit_tan).double()
             dtheta[k0:k0 + used] = acc[:used]
+        allreduce_sum_(dtheta, ctx.group)   # rays sharded over ranks: parameter gradients are sums over all rays
         g_pos_in = g_dir_in = None
         if ctx.jac is not None:
             jac, hit_jac, hit_ray = ctx.jac
@@ -318,10 +320,10 @@ class SimulateNearestFn(torch.autograd.Function):
         for k, (p, i) in enumerate(ctx.thetas):
             grads[where[id(p)]].view(-1)[i] = dtheta[k]
         grads = [g.to(device=d_, dtype=dt) for g, (_, dt, d_) in zip(grads, ctx.param_meta)]
-        return (None,) * 6 + (g_pos_in, g_dir_in) + tuple(grads)
+        return (None,) * 7 + (g_pos_in, g_dir_in) + tuple(grads)
 
 
-def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None):
+def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None, group=None):
     """Run the differentiable nearest-hit bounce loop; returns the five outputs of SimulateNearestFn."""
     thetas = trainable_scalars(elements)
     table = tangent_table(elements, thetas)
@@ -330,7 +332,7 @@ def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None)
         if id(p) not in seen:
             seen.add(id(p))
             params.append(p)
-    return SimulateNearestFn.apply(_detached(rays), prog, table, thetas, max_bounces, capacity, rays._pos, rays._dir, *params)
+    return SimulateNearestFn.apply(_detached(rays), prog, table, thetas, max_bounces, capacity, group, rays._pos, rays._dir, *params)
 
 
 class SpotLossFn(torch.autograd.Function):

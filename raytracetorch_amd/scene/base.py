@@ -188,7 +188,8 @@ class Scene(nn.Module):
                                       "carries no gradient; trace under torch.no_grad()")
         prog = self._program()
         pos, dir_, inten, hit, keys = AG.simulate_nearest_with_grad(self.elements, rays, prog, max_bounces,
-                                                                    getattr(self, "_hit_capacity", None))
+                                                                    getattr(self, "_hit_capacity", None),
+                                                                    group=getattr(self, "grad_group", None))
         rays._pos, rays._dir, rays.intensity = pos, dir_, inten
         if P.n_sensor_slots(prog) > 0:
             self._deliver_sensor_hits(prog, rays, hit, keys)
