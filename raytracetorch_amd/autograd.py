@@ -35,14 +35,16 @@ _mask_cache = {}
 
 
 def _mask_list(mask: torch.Tensor):
-    """Host copy of a gradient mask; masks are constant buffers, so a device-resident one is fetched once."""
+    """Host copy of a gradient mask; masks are constant buffers, so a device-resident one is fetched once.  The
+    entry keeps a weak reference to the tensor it was made from: an id can be reused after that tensor died."""
+    import weakref
     key = (id(mask), mask.data_ptr(), mask._version)
     hit = _mask_cache.get(key)
-    if hit is None:
+    if hit is None or hit[0]() is not mask:
         if len(_mask_cache) > 1024:
             _mask_cache.clear()
-        hit = _mask_cache[key] = mask.reshape(-1).tolist()
-    return hit
+        hit = _mask_cache[key] = (weakref.ref(mask), mask.reshape(-1).tolist())
+    return hit[1]
 
 
 def trainable_scalars(elements) -> List[Tuple[torch.nn.Parameter, int]]:
