@@ -337,3 +337,30 @@ def test_fused_bounce_loop_equals_the_step_loop(ns, case):
         assert torch.equal(ta, tb)
     if case == "cavity":
         assert sa.getHitsTensors()[0].shape[0] > len(rays) and len(sa.hitLocs) > 2    # several crossings per ray
+
+
+def test_more_than_2_to_31_rays(ns):
+    """Index arithmetic beyond 32 bits: a bundle of 2^31 + 1000 rays (72 GB of planes) sampled and traced in one
+    call each; slices at the head, across 2^31 and in the middle are bit-identical to small calls on the same global
+    indices.  Skipped on a device without the memory."""
+    n = 2 ** 31 + 1000
+    if torch.cuda.mem_get_info(0)[0] < 100 * 2 ** 30:
+        pytest.skip("needs about 75 GB of free device memory")
+    b = ns.CollimatedDisk(radius=4.0, ray_id=0, device=DEV,
+                          transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(DEV))
+    rays = b.sample(n, seed=7, offset=0)
+    scene = ns.SequentialScene([scenes.singlet(ns)])
+    spans = [(0, 4096), (2 ** 31 - 2048, 2 ** 31 + 1000), (2 ** 30 + 3, 2 ** 30 + 5000)]
+    small = []
+    with torch.no_grad():
+        for a, e in spans:
+            part = b.sample(e - a, seed=7, offset=a)
+            assert torch.equal(part._pos, rays._pos[:, a:e]) and torch.equal(part._dir, rays._dir[:, a:e]), a
+            small.append(scene.simulate(part))
+        out = scene.simulate(rays)
+    for (a, e), s in zip(spans, small):
+        assert torch.equal(out._pos[:, a:e], s._pos) and torch.equal(out._dir[:, a:e], s._dir), a
+        assert torch.equal(out.intensity[a:e], s.intensity), a
+    assert int((out.intensity > 0).sum()) == n   # the disk of radius 4 passes the 10-wide lens completely
+    del rays, out
+    torch.cuda.empty_cache()
