@@ -209,11 +209,7 @@ class TraceSeqFn(torch.autograd.Function):
         if ctx.needs_input_grad[5] or ctx.needs_input_grad[6]:
             adj = _ray_adjoint(ctx.rays_in, ctx.prog, g_pos, g_dir, g_sens)
             g_pos_in, g_dir_in = adj[:3], adj[3:]
-        grads = [torch.zeros(shape, dtype=torch.float64, device=dtheta.device) for shape, _, _ in ctx.param_meta]
-        where = {pid: k for k, pid in enumerate(ctx.param_ids)}
-        for k, (p, i) in enumerate(ctx.thetas):
-            grads[where[id(p)]].view(-1)[i] = dtheta[k]
-        grads = [g.to(device=dev, dtype=dt) for g, (_, dt, dev) in zip(grads, ctx.param_meta)]
+        grads = _assemble_grads(dtheta, ctx.thetas, ctx.param_meta, ctx.param_ids)
         return (None, None, None, None, None, g_pos_in, g_dir_in, *grads)
 
 
@@ -233,7 +229,7 @@ def _detached(rays):
 def trace_sequential_with_grad(elements, rays, prog, group=None):
     """Run the differentiable trace of `rays` (whose planes may carry a graph); returns the six outputs of
     TraceSeqFn."""
-    thetas = trainable_scalars(elements)
+    thetas = _cached_scalars(elements)
     table = tangent_table(elements, thetas)
     params, seen = [], set()
     for p, _ in thetas:
@@ -317,17 +313,13 @@ class SimulateNearestFn(torch.autograd.Function):
             if g_hit is not None and hit_jac.shape[0]:
                 adj.index_add_(1, hit_ray, torch.einsum("mc,mcj->jm", g_hit, hit_jac))
             g_pos_in, g_dir_in = adj[:3], adj[3:]
-        grads = [torch.zeros(shape, dtype=torch.float64, device=dev) for shape, _, _ in ctx.param_meta]
-        where = {pid: k for k, pid in enumerate(ctx.param_ids)}
-        for k, (p, i) in enumerate(ctx.thetas):
-            grads[where[id(p)]].view(-1)[i] = dtheta[k]
-        grads = [g.to(device=d_, dtype=dt) for g, (_, dt, d_) in zip(grads, ctx.param_meta)]
+        grads = _assemble_grads(dtheta, ctx.thetas, ctx.param_meta, ctx.param_ids)
         return (None,) * 7 + (g_pos_in, g_dir_in) + tuple(grads)
 
 
 def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None, group=None):
     """Run the differentiable nearest-hit bounce loop; returns the five outputs of SimulateNearestFn."""
-    thetas = trainable_scalars(elements)
+    thetas = _cached_scalars(elements)
     table = tangent_table(elements, thetas)
     params, seen = [], set()
     for p, _ in thetas:
@@ -393,69 +385,109 @@ def _chunks(table):
         yield k0, used, padded
 
 
+def _assemble_grads(dtheta, thetas, param_meta, param_ids):
+    """Per-parameter gradient tensors from the flat vector d(loss)/d(theta_k).  Parameters that live on the device
+    of `dtheta` get theirs by one scatter on that device, with no synchronisation (the host may run ahead into the
+    next step); otherwise one device-to-host transfer and the scatter on the host."""
+    sizes = [int(np.prod(shape, dtype=np.int64)) for shape, _, _ in param_meta]
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    where = {pid: k for k, pid in enumerate(param_ids)}
+    dst = [int(starts[where[id(p)]]) + int(i) for p, i in thetas]
+    if param_meta and all(dev == dtheta.device for _, _, dev in param_meta):
+        flat = torch.zeros(int(starts[-1]), dtype=torch.float64, device=dtheta.device)
+        if dst:
+            flat.index_copy_(0, torch.tensor(dst, dtype=torch.int64).to(dtheta.device, non_blocking=True), dtheta)
+    else:
+        flat = torch.zeros(int(starts[-1]), dtype=torch.float64)
+        if dst:
+            flat[torch.tensor(dst, dtype=torch.int64)] = dtheta.cpu()
+    return [flat[starts[k]:starts[k + 1]].reshape(shape).to(device=dev, dtype=dt)
+            for k, (shape, dt, dev) in enumerate(param_meta)]
+
+
 class FusedSpotLossFn(torch.autograd.Function):
     """Spot-size loss of a sequential scene as ONE differentiable function of the scene parameters
-    (optim/goals.py:144-187): forward = trace + float64 moments, backward = one tangent trace that forms the
-    loss adjoint in the kernel (rtt_trace_seq_spot_grad_f32).  No per-ray adjoint or tangent ever reaches HBM."""
+    (optim/goals.py:144-187): trace + float64 moments + one tangent trace that forms the loss adjoint in the
+    kernel (rtt_trace_seq_spot_grad_f32).  No per-ray adjoint or tangent ever reaches HBM.
+
+    The tangent trace is launched by the forward, right behind the moment passes: it needs nothing from the
+    backward but the scalar upstream gradient, so d(loss)/d(theta) is kept and the backward only scales it.  The
+    device then runs trace, moments and tangent trace back to back while the host is already in the caller's
+    code, instead of idling until the autograd engine gets to this function."""
 
     @staticmethod
-    def forward(ctx, rays_in, prog, table, thetas, group, target, sensor_slot, sens, *params):
+    def forward(ctx, rays_in, prog, table, thetas, group, target, sensor_slot, sens, mom, *params):
         hit, w, mask = sens  # dense record of the sensor slot from the forward trace
-        mom = torch.zeros(4, device=w.device, dtype=torch.float64)
         x, y = hit[0], hit[1]
-        _spot_moments(x, y, w, mask, 0, 0.0, 0.0, 1.0, mom)
-        allreduce_sum_(mom, group)
+        allreduce_sum_(mom, group)   # `mom` holds this rank's first moments (pass 0, launched by the caller)
         W, Sx, Sy, _ = mom.tolist()
         ctx.lit = W > 0.0
         W = max(W, 1e-12)
-        cx, cy = (Sx / W, Sy / W) if target is None else (float(target[0]), float(target[1]))
+        centroid = target is None
+        cx, cy = (Sx / W, Sy / W) if centroid else (float(target[0]), float(target[1]))
         mom[3] = 0.0
         _spot_moments(x, y, w, mask, 1, cx, cy, W, mom)
         loss = allreduce_sum_(mom[3:4].clone(), group)
-        ctx.state = (rays_in, prog, table, thetas, group, target is None, sensor_slot, cx, cy, W)
+        n, dev = len(rays_in), rays_in.device
+        dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
+        if ctx.lit and n:
+            dp = _tangent_program(prog, table, dev)
+            for k0, used, padded in _chunks(table):
+                width = padded.shape[2]
+                tan_dev = torch.from_numpy(padded).to(dev)
+                out = torch.zeros(3 * width + 2, dtype=torch.float64, device=dev)
+                with torch.cuda.device(dev):
+                    code = N.lib().rtt_trace_seq_spot_grad_f32(
+                        N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+                        N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width, int(sensor_slot), cx, cy, W,
+                        N.ptr(out), N.stream_handle(dev))
+                N.check(code, "rtt_trace_seq_spot_grad_f32")
+                allreduce_sum_(out, group)
+                A, Bx, By = out[:width], out[width:2 * width], out[2 * width:3 * width]
+                d = A - out[3 * width] * Bx - out[3 * width + 1] * By if centroid else A
+                dtheta[k0:k0 + used] = d[:used]
+        ctx.dtheta, ctx.thetas = dtheta, thetas
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
         return loss.reshape(()).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        rays_in, prog, table, thetas, group, centroid, slot, cx, cy, W = ctx.state
-        n, dev = len(rays_in), rays_in.device
-        dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
-        dp = _tangent_program(prog, table, dev)
-        for k0, used, padded in _chunks(table):
-            width = padded.shape[2]
-            tan_dev = torch.from_numpy(padded).to(dev)
-            out = torch.zeros(3 * width + 2, dtype=torch.float64, device=dev)
-            with torch.cuda.device(dev):
-                code = N.lib().rtt_trace_seq_spot_grad_f32(
-                    N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
-                    N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width, int(slot), cx, cy, W,
-                    N.ptr(out), N.stream_handle(dev))
-            N.check(code, "rtt_trace_seq_spot_grad_f32")
-            allreduce_sum_(out, group)
-            A, Bx, By = out[:width], out[width:2 * width], out[2 * width:3 * width]
-            d = A - out[3 * width] * Bx - out[3 * width + 1] * By if centroid else A
-            dtheta[k0:k0 + used] = d[:used]
-        dtheta = dtheta * g.to(torch.float64)
-        grads = [torch.zeros(shape, dtype=torch.float64, device=dev) for shape, _, _ in ctx.param_meta]
-        where = {pid: k for k, pid in enumerate(ctx.param_ids)}
-        for k, (p, i) in enumerate(thetas):
-            grads[where[id(p)]].view(-1)[i] = dtheta[k]
-        grads = [gr.to(device=d_, dtype=dt) for gr, (_, dt, d_) in zip(grads, ctx.param_meta)]
-        return (None,) * 8 + tuple(grads)
+        grads = _assemble_grads(ctx.dtheta * g.to(torch.float64), ctx.thetas, ctx.param_meta, ctx.param_ids)
+        return (None,) * 9 + tuple(grads)
+
+
+_scalars_cache = {}
+
+
+def _cached_scalars(elements):
+    """trainable_scalars(elements), re-derived only when the elements or their requires_grad flags change (walking
+    the module trees costs as much as launching a trace)."""
+    import weakref
+    params = [p for el in elements for p in el.parameters()]
+    key = (tuple(id(el) for el in elements), tuple(id(p) for p in params), tuple(p.requires_grad for p in params))
+    hit = _scalars_cache.get(key[0])
+    if hit is None or hit[0] != key or any(r() is None for r in hit[1]):
+        if len(_scalars_cache) > 64:
+            _scalars_cache.clear()
+        hit = _scalars_cache[key[0]] = (key, [weakref.ref(p) for p in params], trainable_scalars(elements))
+    return hit[2]
 
 
 def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None):
     """Differentiable spot-size loss of a bundle already traced (forward only, no graph) through `prog`;
     `sens` = (hit [3,N], w [N], mask [N]) of the sensor slot, `rays` the *input* bundle of that trace."""
-    thetas = trainable_scalars(elements)
+    hit, w, mask = sens
+    # first moments right behind the trace; the host work below overlaps both kernels
+    mom = torch.zeros(4, device=w.device, dtype=torch.float64)
+    _spot_moments(hit[0], hit[1], w, mask, 0, 0.0, 0.0, 1.0, mom)
+    thetas = _cached_scalars(elements)
     table = tangent_table(elements, thetas)
     params, seen = [], set()
     for p, _ in thetas:
         if id(p) not in seen:
             seen.add(id(p))
             params.append(p)
-    loss = FusedSpotLossFn.apply(rays, prog, table, thetas, group, target, sensor_slot, sens, *params)
+    loss = FusedSpotLossFn.apply(rays, prog, table, thetas, group, target, sensor_slot, sens, mom, *params)
     # no lit hit on any rank: the reference skips such a bundle (optim/goals.py:165-167)
     return loss if loss.grad_fn is None or loss.grad_fn.lit else None

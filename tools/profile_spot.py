@@ -54,3 +54,4 @@ for _ in range(20):
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("cumtime").print_stats("raytracetorch_amd|run_backward|tolist", 40)
