@@ -22,5 +22,12 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     if group is None:
         return t
     import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo is the rehearsal backend (two ranks on one GPU, CPU tests); its own staging of device tensors has
+        # been seen to hang when two processes share a GPU, and these sums are a few doubles: reduce them on the host
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+        return t
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
