@@ -31,3 +31,33 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
         return t
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def gather_sensor_hits(sensor, group=None, ray_id=None):
+    """`Sensor.getHitsTensors` over all ranks of `group` (elements/sensor.py:46-65): every rank gets the hit lists
+    of all ranks, concatenated in rank order, i.e. in the order of the contiguous ray ranges the ranks own.  The
+    lists have different lengths per rank, so sizes are exchanged first and the rows travel padded to the longest;
+    meant for inspection at small sizes, the optimisation path exchanges only sums."""
+    locs, inten, ids = sensor.getHitsTensors(ray_id) if sensor.hitLocs else (
+        torch.zeros((0, 3)), torch.zeros((0,)), torch.zeros((0,), dtype=torch.int8))
+    if group is None:
+        return locs, inten, ids
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    on_host = dist.get_backend(group) == "gloo"
+    dev = torch.device("cpu") if on_host else locs.device
+    count = torch.tensor([locs.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c) for c in counts]
+    longest = max(counts)
+    # one padded [longest, 5] float32 block per rank: x, y, z, intensity, id
+    mine = torch.zeros((longest, 5), dtype=torch.float32, device=dev)
+    if locs.shape[0]:
+        mine[:locs.shape[0], :3] = locs.detach().to(dev, torch.float32)
+        mine[:locs.shape[0], 3] = inten.detach().to(dev, torch.float32)
+        mine[:locs.shape[0], 4] = ids.to(dev, torch.float32)
+    blocks = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(blocks, mine, group=group)
+    rows = torch.cat([b[:c] for b, c in zip(blocks, counts)]).to(locs.device)
+    return rows[:, :3].contiguous(), rows[:, 3].contiguous(), rows[:, 4].to(torch.int8)

@@ -97,3 +97,43 @@ def test_sharded_spot_loss_equals_single_process(target):
         assert torch.allclose(gx, want_gx[lo:hi], rtol=1e-4, atol=1e-7)
         assert torch.allclose(gy, want_gy[lo:hi], rtol=1e-4, atol=1e-7)
         assert dtheta == [3.0, 4.0]
+
+
+class _FakeSensor:
+    """The hit lists of a Sensor (elements/sensor.py:22-65) without a device."""
+
+    def __init__(self, locs, inten, ids):
+        self.hitLocs = [locs] if locs.shape[0] else []
+        self._all = (locs, inten, ids)
+
+    def getHitsTensors(self, ray_id=None):
+        locs, inten, ids = self._all
+        if ray_id is not None:
+            m = ids == int(ray_id)
+            return locs[m], inten[m], ids[m]
+        return locs, inten, ids
+
+
+def _gather_worker(rank, world, port, sizes, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        m = sizes[rank]
+        sensor = _FakeSensor(torch.randn(m, 3, generator=g), torch.rand(m, generator=g), torch.full((m,), rank, dtype=torch.int8))
+        locs, inten, ids = sharding.gather_sensor_hits(sensor, dist.group.WORLD)
+        ret[rank] = (locs, inten, ids, sensor._all)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [(5, 9), (0, 4), (3, 0)])
+def test_sensor_hits_gathered_over_ranks(sizes):
+    ret = mp.Manager().dict()
+    mp.spawn(_gather_worker, args=(2, _free_port(), sizes, ret), nprocs=2, join=True)
+    want = [torch.cat([ret[r][3][k] for r in range(2)]) for k in range(3)]
+    for rank in range(2):
+        for got, w in zip(ret[rank][:3], want):
+            assert got.dtype == w.dtype and torch.equal(got, w)
+    assert tuple(want[0].shape) == (sum(sizes), 3)
