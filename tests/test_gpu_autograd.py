@@ -244,6 +244,11 @@ def test_differentiable_bounces_equal_the_plain_ones(ns):
         plain.simulate()
     assert (with_grad - plain.rays.pos).abs().max() < 1e-5
     assert (hits - parts2[2].getHitsTensors()[0]).abs().max() < 1e-5
+    tight, parts3 = _folded_scene(ns, g)
+    tight._hit_capacity = 16   # far fewer slots than sensor crossings: the launch is repeated with the room it asked for
+    tight.simulate()
+    assert torch.equal(tight.rays.pos.detach(), with_grad)
+    assert torch.equal(parts3[2].getHitsTensors()[0].detach(), hits)
     one, _ = _folded_scene(ns, g)
     one.step()
     assert one.rays._pos.requires_grad
