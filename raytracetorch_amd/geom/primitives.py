@@ -194,3 +194,10 @@ class Cone(Surface):
     def _diff_geom(self):
         z = torch.zeros_like(self.slope)
         return torch.stack([self.slope, self.slope * self.slope, z, z])
+
+
+class WedgeYZ(Cone):
+    """Declared and refused in the reference as well (geom/primitives.py:500-503)."""
+
+    def __init__(self):
+        raise NotImplementedError()
