@@ -26,7 +26,7 @@ for f in find("*counter_collection.csv"):
             agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print(f"\n## counters ({os.path.relpath(f, root)})  [mean per dispatch]")
     for k, cs in agg.items():
-        if "trace_seq" not in k and "step_nearest" not in k and "ray_cast" not in k:
+        if not any(t in k for t in ("trace_seq", "simulate_nearest", "ray_cast", "spot_moments", "sample_bundle")):
             continue
         for c, v in cs.items():
             print(f"  {k[:50]:50s} {c:28s} n={len(v):3d} mean={sum(v) / len(v):.6g}")

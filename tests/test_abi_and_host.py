@@ -74,6 +74,25 @@ def test_entry_points_validate_before_touching_the_gpu():
     assert lib.rtt_intersect_test_f32(p, p, 8, 8, p, hp, 1, 0, 8, 0) == E_NULL
     assert lib.rtt_surface_forward_f32(p, p, 8, 8, p, hp, 64, 0, 0, 0, 0, 0, 0, 8, 0) == E_SIZE
     assert lib.rtt_spot_moments_f32(p, p, p, 0, 8, 2, 0.0, 0.0, 1.0, p, 0) == E_SIZE
+    # differentiable bounce loop: host copy of the program required, n_theta in {2,4,6,8}, ray seeds need >= 6
+    args = lambda hp_, k, seed: (p, p, p, 8, p, p, p, 8, 8, p, hp_, 1, 3, p, k, seed, p, p, p, p, p, 8, 0)
+    assert lib.rtt_simulate_nearest_tangent_f32(*args(0, 8, 0)) == E_NULL
+    assert lib.rtt_simulate_nearest_tangent_f32(*args(hp, 5, 0)) == E_SIZE
+    assert lib.rtt_simulate_nearest_tangent_f32(*args(hp, 4, 1)) == E_SIZE
+    assert lib.rtt_simulate_nearest_tangent_f32(p, p, p, 8, p, p, p, 8, 0, p, hp, 1, 3, p, 8, 1, p, p, p, p, p, 8, 0) == 0
+    # per-ray adjoint of the sequential trace
+    assert lib.rtt_trace_seq_ray_adjoint_f32(p, p, p, 8, 8, p, hp, 1, 0, p, p, 8, 0, 0, p, 8, 0) == E_NULL     # no zero table
+    assert lib.rtt_trace_seq_ray_adjoint_f32(p, p, p, 8, 8, p, hp, 1, p, p, p, 4, 0, 0, p, 8, 0) == E_SIZE     # ld_adj < n
+    assert lib.rtt_trace_seq_ray_adjoint_f32(p, p, p, 8, 0, p, hp, 1, p, p, p, 8, 0, 0, p, 8, 0) == 0
+    # sources: kinds, and the sub-kinds of a panel
+    src = _native.RttSource()
+    sp = ctypes.addressof(src)
+    src.kind = 9
+    assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 8, 0) == E_KIND
+    src.kind, src.area_kind = 7, 2
+    assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 8, 0) == E_KIND
+    src.area_kind, src.emit_kind = 1, 1
+    assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 0, 0) == 0
     assert lib.rtt_strerror(E_KIND).decode().startswith("surface record")
     assert lib.rtt_tune(0, 3) == E_SIZE and lib.rtt_tune(0, 2) == 0
 
