@@ -1130,8 +1130,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < io.n; i += stride) {
-    Ray<float> r0 = load_ray<float>(io, i);
+  // The visit below is a few thousand cycles of arithmetic at two wavefronts per SIMD, too few to hide a load:
+  // the planes of the lane's next ray are requested before the arithmetic of the current one starts.
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  Ray<float> ahead = load_ray<float>(io, i < io.n ? i : 0);
+  for (; i < io.n; i += stride) {
+    const Ray<float> r0 = ahead;
+    if (i + stride < io.n) ahead = load_ray<float>(io, i + stride);
     Ray<T> r;
     if (PER_RAY) {
       r.p = {unit_seed<K>(r0.p.x, 0), unit_seed<K>(r0.p.y, 1), unit_seed<K>(r0.p.z, 2)};
