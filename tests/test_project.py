@@ -84,3 +84,31 @@ def test_loaded_scene_steps_like_the_reference(ns):
     scene2 = rta.load_scene(RTT)
     assert scene2.rays._pos.is_cuda and len(scene2.rays) == 2560
     scene2.simulate()
+
+
+def test_project_with_the_other_source_families(tmp_path, ns):
+    """A project file naming the beam, panel and particle sources (rays/beam.py, rays/panels.py, rays/particle.py of
+    the reference) builds them, nested emission model included (CPU: only construction and the torch sampler)."""
+    import raytracetorch_amd as rtt
+    tf = {"class": "RayTransformBundle", "params": {"translation": [0.0, 0.0, -30.0]}}
+    bundles = [
+        {"name": "beam", "class": "GaussianBeam", "params": {"diameter_1e2_x": 2.0, "diameter_1e2_y": 1.0, "ray_id": 1, "transform": tf}},
+        {"name": "panel", "class": "RectangularPanel",
+         "params": {"width": 3.0, "height": 1.0, "ray_id": 2, "transform": tf,
+                    "emission": {"class": "SolidAngleEmission", "params": {"cone_angle": 0.3}}}},
+        {"name": "ring", "class": "RingSource", "params": {"radius_inner": 1.0, "radius_outer": 2.0, "ray_id": 3, "transform": tf}},
+        {"name": "ball", "class": "LambertianSphere", "params": {"radius": 0.5, "ray_id": 4, "transform": tf}},
+        {"name": "dust", "class": "RayleighScatter", "params": {"ray_id": 5, "transform": tf}},
+    ]
+    elements = [{"name": "lens", "class": "SingletLens",
+                 "params": {"c1": 0.05, "c2": -0.05, "d": 10.0, "t": 3.0, "ior_glass": 1.5}}]
+    path = str(tmp_path / "sources.rtt")
+    rtt.save_project(path, [{"config": e} for e in elements], [{"config": b, "N_rays": 64} for b in bundles], {"Nbounces": 3})
+    scene = rtt.load_scene(path, device="cpu")
+    assert [type(b).__name__ for b in scene.bundles] == [b["class"] for b in bundles]
+    panel = scene.bundles[1]
+    assert type(panel.emission).__name__ == "SolidAngleEmission" and abs(panel.emission.cone_angle - 0.3) < 1e-12
+    assert panel._source()[0] == 7 and panel._source()[3] == 1      # device description: panel source, cone emission
+    assert scene.rays is not None and len(scene.rays) == 5 * 64
+    assert sorted(set(scene.rays.id.tolist())) == [1, 2, 3, 4, 5]
+    assert scene.Nbounces == 3
