@@ -111,7 +111,10 @@ def ptr(t):
 
 
 def stream_handle(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw handle of torch's current stream on `device` (the launch stream of every entry point)."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(index)
 
 
 class DeviceProgram:

@@ -28,8 +28,11 @@ class Sensor(Element):
 
     # ---- recording --------------------------------------------------------------------------
     def reset(self):
-        self._locs, self._inten, self._ids = [], [], []
-        self._dense = []  # (hit planes [3,N], w [N], mask [N] uint8, id [N]) per visit, not yet compacted
+        # plain attributes, set past nn.Module.__setattr__ (which costs microseconds per assignment and is called
+        # once per trace by the optimisation goals)
+        d = self.__dict__
+        d["_locs"], d["_inten"], d["_ids"] = [], [], []
+        d["_dense"] = []  # (hit planes [3,N], w [N], mask [N] uint8, id [N]) per visit, not yet compacted
 
     def _record_dense(self, hit_planes, w, mask, ids):
         self._dense.append((hit_planes, w, mask, ids))
@@ -49,7 +52,7 @@ class Sensor(Element):
             self._locs.append(hit[:, m].t())
             self._inten.append(w[m])
             self._ids.append(ids[m])
-        self._dense = []
+        self.__dict__["_dense"] = []
 
     @property
     def hitLocs(self):

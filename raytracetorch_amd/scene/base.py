@@ -114,16 +114,21 @@ class Scene(nn.Module):
             prog["seed"][stochastic] = (key & 0xFFFFFFFF, key >> 32)
         return prog
 
-    def _fuzzy_slots(self, prog):
-        """{sensor slot: intensity function} of the records whose functor is a Fuzzy filter."""
-        out = {}
-        for rec in prog:
-            k = int(rec["sensor_slot"])
-            if k >= 0:
-                fn = self.elements[int(rec["element_id"])].surface_functions[int(rec["surface_id"])]
-                if hasattr(fn, "block_function"):
-                    out[k] = fn.block_function
-        return out
+    def _slot_plan(self, prog):
+        """[(sensor slot, element, intensity function of a Fuzzy filter or None)] in program order, kept while the
+        element list is the same (the per-record walk costs as much as a small launch)."""
+        key = (self._element_params()[0], prog.shape[0])   # slots depend on the element list, not on parameter values
+        plan = self.__dict__.get("_slot_plan_cache")
+        if plan is None or plan[0] != key:
+            rows = []
+            for rec in prog:
+                k = int(rec["sensor_slot"])
+                if k >= 0:
+                    el = self.elements[int(rec["element_id"])]
+                    fn = el.surface_functions[int(rec["surface_id"])]
+                    rows.append((k, el, getattr(fn, "block_function", None)))
+            plan = self.__dict__["_slot_plan_cache"] = (key, rows)
+        return plan[1]
 
     def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask, dst=None):
         """Hand the dense records of a trace to the sensors.  Slots are numbered in program order; a Fuzzy
@@ -132,21 +137,17 @@ class Scene(nn.Module):
         (phys/filter.py:36-50 inside scene/sequential.py:12-36)."""
         if sens_hit is None:
             return
-        fuzzy = self._fuzzy_slots(prog)
         factor = None
-        for rec in prog:
-            k = int(rec["sensor_slot"])
-            if k < 0:
-                continue
+        for k, el, fuzzy in self._slot_plan(prog):
             if factor is not None:
                 sens_w[k] *= factor
-            if k in fuzzy:
+            if fuzzy is not None:
                 with torch.no_grad():
-                    f = fuzzy[k](sens_hit[k].t()).to(sens_w.dtype).reshape(-1)
+                    f = fuzzy(sens_hit[k].t()).to(sens_w.dtype).reshape(-1)
                     f = torch.where(sens_mask[k].bool(), f, torch.ones_like(f))
                 factor = f if factor is None else factor * f
             else:
-                self.elements[int(rec["element_id"])]._record_dense(sens_hit[k], sens_w[k], sens_mask[k], rays.id)
+                el._record_dense(sens_hit[k], sens_w[k], sens_mask[k], rays.id)
         if factor is not None:
             dst = rays if dst is None else dst   # the rays that hold the result of the trace
             dst.intensity = dst.intensity * factor
