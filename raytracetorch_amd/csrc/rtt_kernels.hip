@@ -1997,16 +1997,18 @@ struct BundleOut {
   float* __restrict__ wavelength;
 };
 
-DI void store_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V3<float> p, V3<float> d) {
-  // RayTransformBundle.transform_: pos @ R^T + t, dir @ R^T (geom/transform.py:259-262)
+// local sample -> global ray: RayTransformBundle.transform_ (pos @ R^T + t, dir @ R^T, geom/transform.py:259-262)
+// and F.normalize of Rays.__post_init__ (dir / max(|dir|, 1e-12), rays/ray.py:22-25)
+DI void pose_sampled_ray(const RttSource& src, V3<float> p, V3<float> d, V3<float>& pg, V3<float>& dg) {
   const float* R = src.R;
-  const V3<float> pg = {p.x * R[0] + p.y * R[1] + p.z * R[2] + src.t[0], p.x * R[3] + p.y * R[4] + p.z * R[5] + src.t[1],
-                        p.x * R[6] + p.y * R[7] + p.z * R[8] + src.t[2]};
-  V3<float> dg = {d.x * R[0] + d.y * R[1] + d.z * R[2], d.x * R[3] + d.y * R[4] + d.z * R[5],
-                  d.x * R[6] + d.y * R[7] + d.z * R[8]};
-  // Rays.__post_init__: F.normalize(dir) = dir / max(|dir|, 1e-12) (rays/ray.py:22-25)
+  pg = {p.x * R[0] + p.y * R[1] + p.z * R[2] + src.t[0], p.x * R[3] + p.y * R[4] + p.z * R[5] + src.t[1],
+        p.x * R[6] + p.y * R[7] + p.z * R[8] + src.t[2]};
+  dg = {d.x * R[0] + d.y * R[1] + d.z * R[2], d.x * R[3] + d.y * R[4] + d.z * R[5], d.x * R[6] + d.y * R[7] + d.z * R[8]};
   const float len = fmaxf(sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z), 1e-12f);
   dg = {dg.x / len, dg.y / len, dg.z / len};
+}
+
+DI void write_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V3<float> pg, V3<float> dg) {
   o.pos[i] = pg.x; o.pos[o.ld + i] = pg.y; o.pos[2 * o.ld + i] = pg.z;
   o.dir[i] = dg.x; o.dir[o.ld + i] = dg.y; o.dir[2 * o.ld + i] = dg.z;
   if (o.inten) o.inten[i] = 1.0f;
@@ -2014,18 +2016,47 @@ DI void store_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V
   if (o.wavelength) o.wavelength[i] = 0.0f;
 }
 
-__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, BundleOut o, int64_t n) {
+DI void store_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V3<float> p, V3<float> d) {
+  V3<float> pg, dg;
+  pose_sampled_ray(src, p, d, pg, dg);
+  write_sampled_ray(src, o, i, pg, dg);
+}
+
+// `vec`: the planes are 8-byte aligned with an even leading dimension and the call starts on an even global index,
+// so the two rays of a lane are one 8-byte, non-temporal store per plane (the bundle is written once and read by
+// another kernel).
+__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, BundleOut o, int64_t n, int vec) {
   const uint64_t first_pair = src.offset >> 1;
   const uint64_t pair = first_pair + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const Philox4 rnd = philox4x32_10(pair, src.seed);
+  V3<float> pg[2], dg[2];
+  bool live[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const uint64_t g = 2 * pair + h;  // global ray index
-    if (g < src.offset || g >= src.offset + (uint64_t)n) continue;
+    live[h] = g >= src.offset && g < src.offset + (uint64_t)n;
     V3<float> p, d;
     sample_local(src, unit_uniform(rnd.x[2 * h]), unit_uniform(rnd.x[2 * h + 1]), p, d);
-    store_sampled_ray(src, o, (int64_t)(g - src.offset), p, d);
+    pose_sampled_ray(src, p, d, pg[h], dg[h]);
   }
+  const int64_t i = (int64_t)(2 * pair - src.offset);  // call index of the lane's first ray (-1 when it is not part of the call)
+  if (vec && live[0] && live[1]) {
+    auto put = [](float* plane, int64_t at, float a, float b) {
+      __builtin_nontemporal_store(f2{a, b}, reinterpret_cast<f2*>(plane + at));
+    };
+    put(o.pos, i, pg[0].x, pg[1].x); put(o.pos + o.ld, i, pg[0].y, pg[1].y); put(o.pos + 2 * o.ld, i, pg[0].z, pg[1].z);
+    put(o.dir, i, dg[0].x, dg[1].x); put(o.dir + o.ld, i, dg[0].y, dg[1].y); put(o.dir + 2 * o.ld, i, dg[0].z, dg[1].z);
+    if (o.inten) put(o.inten, i, 1.0f, 1.0f);
+    if (o.wavelength) put(o.wavelength, i, 0.0f, 0.0f);
+    if (o.id) {
+      const uint16_t two = (uint16_t)((uint8_t)src.ray_id * 0x0101u);
+      __builtin_nontemporal_store(two, reinterpret_cast<uint16_t*>(o.id + i));
+    }
+    return;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (live[h]) write_sampled_ray(src, o, i + h, pg[h], dg[h]);
 }
 
 // four uniforms per ray: one Philox block each
@@ -2650,8 +2681,11 @@ int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t 
   }
   const uint64_t first_pair = src->offset >> 1, last_pair = (src->offset + (uint64_t)n - 1) >> 1;
   const uint64_t pairs = last_pair - first_pair + 1;
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (src->offset % 2 == 0) && (ld % 2 == 0) && aligned8(pos) && aligned8(dir) && aligned8(inten) &&
+                  aligned8(wavelength) && (reinterpret_cast<uintptr_t>(id) & 1u) == 0;
   hipLaunchKernelGGL(k_sample_bundle, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                     *src, o, n);
+                     *src, o, n, vec);
   return launch_status();
 }
 
