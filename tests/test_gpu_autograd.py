@@ -390,3 +390,35 @@ def test_differentiable_paths_on_degenerate_inputs(ns):
     lens.shape.surfaces[0].c.grad = None
     res.pos.sum().backward()
     assert float(lens.shape.surfaces[0].c.grad) == 0.0
+
+
+def test_gui_style_optimisation_loop(ns):
+    """What the reference's workbench does (gui/workbench.py:425-452, :683-707): rays wrapped in Paths, one
+    Scene.step() per bounce with trainable elements and grad mode on, then an RMS spot loss on the sensor hits and
+    backward().  Same loss and gradients as one simulate() without the wrapper."""
+    g = golden("grad_naive")
+    results = []
+    for wrapped in (True, False):
+        scene, parts = _folded_scene(ns, g)
+        if wrapped:
+            paths = ns.Paths(scene.rays)
+            scene.rays = paths
+            for _ in range(9):
+                if not (scene.rays.intensity > 0).any():
+                    break
+                scene.step()
+            assert len(paths.get_history()) == 1 + 7          # start + one snapshot per bounce that moved a ray
+            assert paths.unwrap()._pos.requires_grad
+        else:
+            scene.Nbounces = 9
+            scene.simulate()
+        locs, w, _ = parts[2].getHitsTensors()
+        xy, ws = locs[:, :2], w.sum().clamp(min=1e-12)
+        cx, cy = (xy[:, 0] * w).sum() / ws, (xy[:, 1] * w).sum() / ws
+        rms = torch.sqrt(((xy[:, 0] - cx) ** 2 + (xy[:, 1] - cy) ** 2) * w / ws).sum()
+        rms.backward()
+        results.append((float(rms.detach()), scenes.folded_gradients(*parts)))
+    assert rel(results[0][0], results[1][0]) < 1e-6
+    for k in results[0][1]:
+        a, b = results[0][1][k], results[1][1][k]
+        assert torch.allclose(a, b, rtol=5e-4, atol=2e-4 * float(b.abs().max()) + 1e-7), (k, a, b)
