@@ -385,6 +385,26 @@ def gen_fuzzy(ns):
           out["seq_s1_w"].shape, out["step5_intensity"].mean(), out["step_s1_w"].shape, (out["step5_intensity"] == 0).sum())
 
 
+def gen_manual_spot(ns):
+    """tests/test_optimize_singlet.py:66-116 of the reference: loss and gradients of its closure, float32 / float64."""
+    torch.manual_seed(16)
+    rays = ns.CollimatedDisk(5.0, 1, transform=ns.RayTransformBundle(translation=[0, 0, -10])).sample(4096)
+    out = rays_arrays(rays, "in_")
+    for dtype, dt in ((torch.float32, "f32"), (torch.float64, "f64")):
+        lens = scenes.manual_lens(ns)
+        if dtype == torch.float64:
+            lens.double()
+        r = ns.Rays.initialize(rays.pos.to(dtype), rays.dir.to(dtype), dtype=dtype)
+        loss = scenes.manual_spot_loss(ns, lens, r)
+        loss.backward()
+        s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+        got = dict(loss=loss.detach(), c1=s0.c.grad, c2=s1.c.grad, t0=s0.transform.trans.grad, t1=s1.transform.trans.grad,
+                   ior=lens.ior_glass.grad)
+        out.update({f"{dt}_{k}": npy(v) for k, v in got.items()})
+        print("manual_spot", dt, {k: np.round(npy(v), 5).tolist() for k, v in got.items()})
+    np.savez_compressed(os.path.join(OUT, "manual_spot.npz"), **out)
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -520,6 +540,8 @@ def main():
         return gen_paraxial(ns)
     if sys.argv[1:] == ["spot_target"]:
         return gen_spot_target(ns)
+    if sys.argv[1:] == ["manual_spot"]:
+        return gen_manual_spot(ns)
     if sys.argv[1:] == ["fuzzy"]:
         return gen_fuzzy(ns)
     if sys.argv[1:] == ["tilt"]:
@@ -548,6 +570,7 @@ def main():
     gen_paraxial(ns)
     gen_spot_target(ns)
     gen_fuzzy(ns)
+    gen_manual_spot(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

@@ -2272,7 +2272,9 @@ int check_program(const RttSurface* host, int n_surf, bool* any_sensor, int* n_s
         if (host[first + q].element_id != S.element_id || host[first + q].surface_id != q) return RTT_E_KIND;
     }
     if (S.phys_kind < RTT_PHYS_TRANSMIT || S.phys_kind > RTT_PHYS_FRESNEL) return RTT_E_KIND;
-    if ((S.shape_kind != RTT_SHP_NONE) != ((S.flags & RTT_F_HAS_SHAPE) != 0)) return RTT_E_KIND;
+    // a shape bound lives in the element frame; the two-level transform without a shape bound is allowed (one surface
+    // of an element visited the way Shape.forward does, geom/shape.py:61-87)
+    if (S.shape_kind != RTT_SHP_NONE && !(S.flags & RTT_F_HAS_SHAPE)) return RTT_E_KIND;
     if ((S.flags & RTT_F_SENSOR) && any_sensor) {  // slots only matter to entry points that record
       if (S.sensor_slot < 0 || S.sensor_slot >= RTT_MAX_SURFACES) return RTT_E_SIZE;
       if (any_sensor) *any_sensor = true;

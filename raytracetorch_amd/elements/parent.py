@@ -42,10 +42,26 @@ class Element(nn.Module):
         return K.surface_forward(rays, self._record(surf_idx)[None], 0, want_phys=True)
 
     def forward(self, rays, surf_idx):
+        """(hit_global [N,3], new_dir [N,3], intensity multiplier [N]) of surface `surf_idx` for every ray
+        (elements/parent.py:44-58).  Under grad mode the first two are differentiable with respect to the element's
+        trainable parameters and to the rays (tests/test_optimize_singlet.py:66-116 of the reference chains two such
+        calls and back-propagates a spot loss)."""
         o = self._forward_full(rays, surf_idx)
         fn = self.surface_functions[surf_idx]
         if hasattr(fn, "block_function"):   # Fuzzy: the multiplier is a host-side function of the local hit point
             return o["hit_global"], o["new_dir"], o["imult"] * fn.block_function(o["hit_local"])
+        from .. import autograd as AG
+        if AG.needs_grad([self]) or AG.rays_carry_grad(rays):
+            # the same visit as a one-surface sequential trace, whose backward exists; like Shape.forward it applies no
+            # shape-level bound (geom/shape.py:61-87), and rays without a hit keep what the plain call returned
+            rec = self._record(surf_idx)
+            rec["shape_kind"] = P.SHP_NONE
+            rec["sensor_slot"] = -1
+            rec["flags"] &= ~P.F_SENSOR
+            outs = AG.trace_sequential_with_grad([_OneSurface(self, surf_idx)], rays, rec[None])
+            hit = (o["t"] < float("inf"))[:, None]
+            return (torch.where(hit, outs[0].t(), o["hit_global"]), torch.where(hit, outs[1].t(), o["new_dir"]),
+                    o["imult"])
         return o["hit_global"], o["new_dir"], o["imult"]
 
     # ---- paraxial description (host-side 5x5 matrices on (x, u, y, v, 1); no rays involved) -----------
@@ -61,6 +77,26 @@ class Element(nn.Module):
     def getParaxial(self):
         """([z of each paraxial surface], [its 5x5 matrix]) (elements/parent.py:60-70)."""
         return [self.shape.z], [self._posed(self._paraxial())]
+
+
+class _OneSurface:
+    """One surface of an element where the gradient code expects an element with a one-surface shape."""
+
+    class _Len1:
+        def __len__(self):
+            return 1
+
+    def __init__(self, element, j):
+        self.element, self.j, self.shape = element, j, self._Len1()
+
+    def parameters(self):
+        return self.element.parameters()
+
+    def modules(self):
+        return self.element.modules()
+
+    def _diff_slots(self, _j):
+        return self.element._diff_slots(self.j)
 
 
 class ElementCustom(Element):

@@ -127,6 +127,23 @@ def folded_bundle(ns):
                              transform=ns.RayTransformBundle(translation=[0.0, 0.0, -0.3], rotation=[0.01, -0.01, 0.0]))
 
 
+def manual_spot_loss(ns, lens, rays, target_z=100.0):
+    """The closure of the reference's tests/test_optimize_singlet.py:66-116: two Element calls chained by assigning
+    pos / dir, projection onto the plane z = target_z, mean squared distance from the axis."""
+    p1, d1, _ = lens(rays, surf_idx=0)
+    rays.pos = p1
+    rays.dir = d1
+    p2, d2, _ = lens(rays, surf_idx=1)
+    t_dist = (target_z - p2[:, 2]) / (d2[:, 2] + 1e-6)
+    x, y = p2[:, 0] + t_dist * d2[:, 0], p2[:, 1] + t_dist * d2[:, 1]
+    return torch.mean(x ** 2 + y ** 2)
+
+
+def manual_lens(ns):
+    return ns.SingletLens(c1=0.016667, c2=-0.00283, d=25.4, t=4.0, ior_glass=1.5168, ior_media=1.0, c1_grad=True,
+                          c2_grad=True, t_grad=True, ior_glass_grad=True, inked=False)
+
+
 def soft_edge(hit_local, unit=1.0):
     """Intensity profile of the Fuzzy filter in the goldens: a Gaussian apodisation that is exactly zero far out."""
     r2 = (hit_local[:, 0] ** 2 + hit_local[:, 1] ** 2) / (unit * unit)

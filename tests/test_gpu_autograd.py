@@ -422,3 +422,23 @@ def test_gui_style_optimisation_loop(ns):
     for k in results[0][1]:
         a, b = results[0][1][k], results[1][1][k]
         assert torch.allclose(a, b, rtol=5e-4, atol=2e-4 * float(b.abs().max()) + 1e-7), (k, a, b)
+
+
+def test_chained_element_calls_are_differentiable(ns):
+    """The closure of the reference's tests/test_optimize_singlet.py:66-116: lens(rays, 0), assign pos / dir,
+    lens(rays, 1), project, mean squared radius, backward.  Loss and gradients against the reference's autograd."""
+    g = golden("manual_spot")
+    lens = scenes.manual_lens(ns)
+    rays = ns.Rays.initialize(torch.from_numpy(g["in_pos"]), torch.from_numpy(g["in_dir"])).to(DEV)
+    loss = scenes.manual_spot_loss(ns, lens, rays)
+    assert rel(loss, g["f32_loss"]) < 1e-5
+    loss.backward()
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    got = dict(c1=s0.c.grad, c2=s1.c.grad, t0=s0.transform.trans.grad, t1=s1.transform.trans.grad, ior=lens.ior_glass.grad)
+    for k, v in got.items():
+        assert v is not None, k
+        v = v.detach().cpu().double().numpy().reshape(-1)
+        want, truth = g[f"f32_{k}"].reshape(-1).astype(np.float64), g[f"f64_{k}"].reshape(-1)
+        scale = max(1.0, np.abs(truth).max())
+        for a, b, c in zip(v, want, truth):
+            assert abs(a - b) <= GRAD_TOL * scale or abs(a - c) <= 1.5 * abs(b - c) + 1e-6 * scale, (k, a, b, c)
