@@ -442,3 +442,32 @@ def test_chained_element_calls_are_differentiable(ns):
         scale = max(1.0, np.abs(truth).max())
         for a, b, c in zip(v, want, truth):
             assert abs(a - b) <= GRAD_TOL * scale or abs(a - c) <= 1.5 * abs(b - c) + 1e-6 * scale, (k, a, b, c)
+
+
+def test_doublet_optimisation_example(ns):
+    """The shape of the reference's optimisation example (tests/test_optimization.py: cemented doublet, sensor, three
+    field bundles, spot-size goal plus layout constraints, Adam): the combined loss goes down and every trainable
+    parameter receives a finite gradient in every step."""
+    import math
+    torch.manual_seed(0)
+    lens = ns.DoubletLens(c1=0.05, c2=-0.015, c3=-0.0014, d=25.0, t1=6.0, t2=2.5, ior_glass1=1.517, ior_glass2=1.648,
+                          c1_grad=True, c2_grad=True, c3_grad=True, t1_grad=True, inked=True)
+    sensor = ns.Sensor(ns.Disk(radius=12.0, transform=ns.RayTransform(translation=[0.0, 0.0, 50.0])))
+    scene = ns.SequentialScene([lens, sensor])
+    bundles = [ns.CollimatedDisk(radius=8.0, ray_id=i, device=DEV, transform=ns.RayTransformBundle(
+        rotation=[-math.radians(a), 0.0, 0.0], translation=[0.0, 0.0, -10.0]).to(DEV)) for i, a in enumerate((0.0, 2.0, 4.0))]
+    spot = ns.SpotSizeLoss(sensor, bundles, N_rays=4096)
+    cons = [ns.ThicknessConstraint([lens], 0.5, 15.0, weight=0.05), ns.SpacingConstraint([lens, sensor], 5.0, weight=0.05),
+            ns.SystemLengthConstraint([lens, sensor], 120.0, weight=0.05)]
+    params = [p for p in scene.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=2e-4)
+    history = []
+    for _ in range(25):
+        opt.zero_grad()
+        torch.manual_seed(1)   # the same rays every step, so that the loss is a fixed function of the parameters
+        total = spot(scene) + sum(c() for c in cons)
+        total.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        opt.step()
+        history.append(float(total.detach()))
+    assert history[-1] < history[0] and all(np.isfinite(history))
