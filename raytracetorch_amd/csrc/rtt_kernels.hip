@@ -565,7 +565,7 @@ DI M root_kept(const RV& S, const Frames<T>& f, T r, M ok) {
 // min over the filtered roots (geom/primitives.py:34, geom/bounded.py:34): the column value t (inf on
 // a miss) and `finite` = t < inf.
 template <class C, class RV, class T, class M>
-DI T solve_t(const RV& S, const Frames<T>& f, M& finite) {
+DI T solve_t_any(const RV& S, const Frames<T>& f, M& finite) {
   T t1, t2;
   M ok;
   const T inf = splat<T>(kInf);
@@ -588,6 +588,80 @@ DI T solve_t(const RV& S, const Frames<T>& f, M& finite) {
   const T t = nanmin(sel(g1, t1, inf), sel(g2, t2, inf));
   finite = lt(t, inf);
   return t;
+}
+
+template <class C, class RV, class T, class M>
+DI T solve_t(const RV& S, const Frames<T>& f, M& finite) {
+  return solve_t_any<C>(S, f, finite);
+}
+
+DI V3<float> values(V3<float> v) { return v; }
+template <int K> DI V3<float> values(V3<Dual<K>> v) { return {v.x.v, v.y.v, v.z.v}; }
+
+// Dual-number rays: the root is found on the values (the float path above: same roots, same filters, same choice),
+// and its tangents come from differentiating "t solves A t^2 + B t + C = 0" implicitly,
+//     dt = -(t^2 dA + t dB + dC) / (2 A t + B),
+// with A, B, C the reference's coefficient formulas of the surface kind: the derivative autograd obtains through the
+// closed-form root, at a fraction of the arithmetic (no dual-number square root, reciprocal and second root).  Where
+// the reference takes the linear root -C / B_safe (|A| < 1e-6) the A term is dropped, as it is there.  Planes (one
+// quotient) and cones keep the explicit path.
+template <class C, int K>
+DI Dual<K> solve_t(const RecD<K>& S, const Frames<Dual<K>>& f, bool& finite) {
+  const int sk = C::sk(S.r);
+  if (sk == RTT_SURF_PLANE || sk == RTT_SURF_CONE) return solve_t_any<C>(S, f, finite);
+  const RecF Sv{S.r};
+  const Frames<float> fv = {values(f.pe), values(f.de), values(f.pl), values(f.dl)};
+  const float t = solve_t_any<C>(Sv, fv, finite);
+  Dual<K> out(t);
+  if (!finite) return out;
+  const V3<float> o = fv.pl, d = fv.dl;
+  const V3<float> h = {o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
+  // t^2 dA + t dB + dC = go . d(o) + gd . d(d) + g0 d(geom[i0]) + g1 d(geom[i1]);  den = 2 A t + B
+  V3<float> go, gd;
+  float g0 = 0.0f, g1 = 0.0f, den;
+  int i0 = 0, i1 = 0;
+  if (sk == RTT_SURF_SPHERE) {  // t^2 + b t + c with b = 2 o.d, c = o.o - R^2 (no d.d term in the reference)
+    go = {2.0f * h.x, 2.0f * h.y, 2.0f * h.z};
+    gd = {2.0f * t * o.x, 2.0f * t * o.y, 2.0f * t * o.z};
+    g0 = -1.0f;
+    i0 = 1;
+    den = 2.0f * t + 2.0f * (o.x * d.x + o.y * d.y + o.z * d.z);
+  } else if (sk == RTT_SURF_CYLINDER) {
+    go = {2.0f * h.x, 2.0f * h.y, 0.0f};
+    gd = {t * go.x, t * go.y, 0.0f};
+    g0 = -1.0f;
+    i0 = 1;
+    den = 2.0f * (d.x * d.x + d.y * d.y) * t + 2.0f * (o.x * d.x + o.y * d.y);
+  } else {  // RTT_SURF_QUADRIC, RTT_SURF_QUADRIC_ZY
+    const float c = S.r.geom[0], c1k = S.r.geom[2];
+    const float kx = sk == RTT_SURF_QUADRIC ? 1.0f : 0.0f;
+    const float A = c * (kx * d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
+    const float B = 2.0f * c * (kx * o.x * d.x + o.y * d.y) + 2.0f * c1k * o.z * d.z - 2.0f * d.z;
+    go = {2.0f * c * kx * h.x, 2.0f * c * h.y, 2.0f * c1k * h.z - 2.0f};
+    i0 = 0;
+    i1 = 2;
+    if (fabsf(A) < kEps) {  // the reference's linear root: t = -C / B_safe
+      gd = {t * 2.0f * c * kx * o.x, t * 2.0f * c * o.y, t * (2.0f * c1k * o.z - 2.0f)};
+      g0 = 2.0f * t * (kx * o.x * d.x + o.y * d.y) + (kx * o.x * o.x + o.y * o.y);
+      g1 = 2.0f * t * o.z * d.z + o.z * o.z;
+      den = fabsf(B) < kEps ? kEps : B;
+    } else {
+      gd = {t * go.x, t * go.y, t * go.z};
+      g0 = kx * h.x * h.x + h.y * h.y;
+      g1 = h.z * h.z;
+      den = 2.0f * A * t + B;
+    }
+  }
+  const float s = -1.0f / den;
+  const Dual<K> p0 = S.geom(i0), p1 = S.geom(i1);
+#pragma unroll
+  for (int j = 0; j < K / 2; ++j) {
+    f2 num = go.x * f.pl.x.tp[j] + go.y * f.pl.y.tp[j] + go.z * f.pl.z.tp[j];
+    num += gd.x * f.dl.x.tp[j] + gd.y * f.dl.y.tp[j] + gd.z * f.dl.z.tp[j];
+    num += g0 * p0.tp[j] + g1 * p1.tp[j];
+    out.tp[j] = s * num;
+  }
+  return out;
 }
 
 template <class C, class RV, class T>
