@@ -405,6 +405,31 @@ def gen_manual_spot(ns):
     np.savez_compressed(os.path.join(OUT, "manual_spot.npz"), **out)
 
 
+def gen_grad_plano(ns):
+    """Gradients w.r.t. the curvature of a flat lens face (c = 0, where the reference takes the linear root -C/B of
+    geom/primitives.py:300-318 and autograd differentiates that formula) and of the curved back face; tilted bundle,
+    random projection of the output rays.  Float32 and float64."""
+    torch.manual_seed(20)
+    n = 2048
+    rays = scenes.disk_bundle(ns, radius=3.5, rot=[0.05, -0.03, 0.0]).sample(n)
+    wp, wd = torch.randn(n, 3), torch.randn(n, 3)
+    out = rays_arrays(rays, "in_")
+    out.update(wp=npy(wp), wd=npy(wd))
+    for dtype, dt in ((torch.float32, "f32"), (torch.float64, "f64")):
+        lens = scenes.singlet(ns, c1=0.0, c2=-0.08, c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True)
+        if dtype == torch.float64:
+            lens.double()
+        r = ns.Rays.initialize(rays.pos.to(dtype), rays.dir.to(dtype), dtype=dtype)
+        r = ns.SequentialScene([lens]).simulate(r)
+        obj = (r.pos * wp.to(dtype)).sum() + (r.dir * wd.to(dtype)).sum()
+        obj.backward()
+        s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+        got = dict(obj=obj.detach(), c1=s0.c.grad, c2=s1.c.grad, t0=s0.transform.trans.grad, ior=lens.ior_glass.grad)
+        out.update({f"{dt}_{k}": npy(v) for k, v in got.items()})
+        print("grad_plano", dt, {k: np.round(npy(v), 4).tolist() for k, v in got.items()})
+    np.savez_compressed(os.path.join(OUT, "grad_plano.npz"), **out)
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -542,6 +567,8 @@ def main():
         return gen_spot_target(ns)
     if sys.argv[1:] == ["manual_spot"]:
         return gen_manual_spot(ns)
+    if sys.argv[1:] == ["plano"]:
+        return gen_grad_plano(ns)
     if sys.argv[1:] == ["fuzzy"]:
         return gen_fuzzy(ns)
     if sys.argv[1:] == ["tilt"]:
@@ -571,6 +598,7 @@ def main():
     gen_spot_target(ns)
     gen_fuzzy(ns)
     gen_manual_spot(ns)
+    gen_grad_plano(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

@@ -471,3 +471,24 @@ def test_doublet_optimisation_example(ns):
         opt.step()
         history.append(float(total.detach()))
     assert history[-1] < history[0] and all(np.isfinite(history))
+
+
+def test_gradient_of_a_flat_face_curvature(ns):
+    """c = 0 on the front face: the reference solves the linear equation there (geom/primitives.py:300-318) and its
+    autograd differentiates that formula, not the quadratic root; the tangent kernel follows."""
+    g = golden("grad_plano")
+    lens = scenes.singlet(ns, c1=0.0, c2=-0.08, c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True)
+    rays = ns.Rays.initialize(torch.from_numpy(g["in_pos"]), torch.from_numpy(g["in_dir"])).to(DEV)
+    r = ns.SequentialScene([lens]).simulate(rays)
+    wp, wd = torch.from_numpy(g["wp"]).to(DEV), torch.from_numpy(g["wd"]).to(DEV)
+    obj = (r.pos * wp).sum() + (r.dir * wd).sum()
+    assert rel(obj, g["f32_obj"]) < 1e-5
+    obj.backward()
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    got = dict(c1=s0.c.grad, c2=s1.c.grad, t0=s0.transform.trans.grad, ior=lens.ior_glass.grad)
+    for k, v in got.items():
+        v = v.detach().cpu().double().numpy().reshape(-1)
+        want, truth = g[f"f32_{k}"].reshape(-1).astype(np.float64), g[f"f64_{k}"].reshape(-1)
+        scale = max(1.0, np.abs(truth).max())
+        for a, b, c in zip(v, want, truth):
+            assert abs(a - b) <= GRAD_TOL * scale or abs(a - c) <= 1.5 * abs(b - c) + 1e-6 * scale, (k, a, b, c)
