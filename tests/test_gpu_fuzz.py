@@ -1,6 +1,7 @@
 """GPU: randomly drawn systems (rotated and decentred elements, doublets, cylindrical lenses, stops,
 mirrors, sensor) through the HIP trace, the nearest-hit step and the gradient kernel, against the oracle."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -17,7 +18,7 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("gen", ["random_system", "random_system_extra"])
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTT_FUZZ_FIRST", "0")), int(os.environ.get("RTT_FUZZ_SEEDS", "16"))))
 def test_random_system_sequential_and_nearest(ns, seed, gen):
     els = getattr(scenes, gen)(ns, np.random.default_rng(seed))
     torch.manual_seed(seed)
