@@ -430,6 +430,36 @@ def gen_grad_plano(ns):
     np.savez_compressed(os.path.join(OUT, "grad_plano.npz"), **out)
 
 
+def gen_grad_fuzz(ns):
+    """Gradients of random systems with every parameter trainable, by the reference's autograd (float32 and
+    float64): the element kinds of both random generators, poses with and without rotation."""
+    import math
+    n = 512
+    out = {}
+    for gen in ("random_system", "random_system_extra"):
+        for seed in range(10):
+            torch.manual_seed(100 + seed)
+            rays = scenes.disk_bundle(ns, radius=5.0, z=-15.0, rot=[0.03 * math.sin(seed), 0.02, 0.0]).sample(n)
+            wp, wd, ws = torch.randn(n, 3), torch.randn(n, 3), torch.randn(n, 3)
+            tag = f"{gen}/{seed}"
+            out.update({f"{tag}/in_pos": npy(rays.pos), f"{tag}/in_dir": npy(rays.dir), f"{tag}/wp": npy(wp),
+                        f"{tag}/wd": npy(wd), f"{tag}/ws": npy(ws)})
+            for dtype, dt in ((torch.float32, "f32"), (torch.float64, "f64")):
+                els = getattr(scenes, gen)(ns, np.random.default_rng(seed))
+                if dtype == torch.float64:
+                    for el in els:
+                        el.double()
+                params = scenes.make_all_trainable(els)
+                r = ns.Rays.initialize(rays.pos.to(dtype), rays.dir.to(dtype), dtype=dtype)
+                obj = scenes.fuzz_objective(ns, els, r, wp.to(dtype), wd.to(dtype), ws.to(dtype))
+                obj.backward()
+                out[f"{tag}/{dt}/obj"] = npy(obj.detach())
+                for name, p in params.items():
+                    out[f"{tag}/{dt}/g/{name}"] = npy(torch.zeros_like(p) if p.grad is None else p.grad)
+            print("grad_fuzz", tag, float(out[f"{tag}/f32/obj"]), len(params))
+    np.savez_compressed(os.path.join(OUT, "grad_fuzz.npz"), **out)
+
+
 def gen_bundles(ns):
     """Bundle.sample of the reference, together with the torch.rand values it consumed, in the order the code
     samples (positions first, then directions; one torch.rand of N values per draw, whatever its shape).  The
@@ -567,6 +597,8 @@ def main():
         return gen_spot_target(ns)
     if sys.argv[1:] == ["manual_spot"]:
         return gen_manual_spot(ns)
+    if sys.argv[1:] == ["grad_fuzz"]:
+        return gen_grad_fuzz(ns)
     if sys.argv[1:] == ["plano"]:
         return gen_grad_plano(ns)
     if sys.argv[1:] == ["fuzzy"]:
@@ -599,6 +631,7 @@ def main():
     gen_fuzzy(ns)
     gen_manual_spot(ns)
     gen_grad_plano(ns)
+    gen_grad_fuzz(ns)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)

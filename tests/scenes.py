@@ -380,6 +380,29 @@ def random_system_extra(ns, rng):
     return els
 
 
+def make_all_trainable(els):
+    """requires_grad on every floating-point parameter of the elements (tolerances excepted); returns
+    {name: parameter} with names that are the same in the reference and in the package."""
+    import torch.nn as nn
+    named = dict(nn.ModuleList(els).named_parameters())
+    out = {}
+    for name, p in named.items():
+        if p.is_floating_point() and "epsilon" not in name:
+            p.requires_grad_(True)
+            out[name] = p
+    return out
+
+
+def fuzz_objective(ns, els, rays, wp, wd, ws):
+    """Random projection of the traced rays and of the sensor hits (the last element is the sensor)."""
+    r = ns.SequentialScene(els).simulate(rays)
+    obj = (r.pos * wp).sum() + (r.dir * wd).sum()
+    if els[-1].hitLocs:
+        locs, w, _ = els[-1].getHitsTensors()
+        obj = obj + (locs * ws[: locs.shape[0]] * w[:, None]).sum()
+    return obj
+
+
 # ---------------------------------------------------------------------------------------------
 # ray-source cases (rays/bundle.py)
 # ---------------------------------------------------------------------------------------------
