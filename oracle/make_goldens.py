@@ -456,7 +456,19 @@ def gen_grad_fuzz(ns):
                 out[f"{tag}/{dt}/obj"] = npy(obj.detach())
                 for name, p in params.items():
                     out[f"{tag}/{dt}/g/{name}"] = npy(torch.zeros_like(p) if p.grad is None else p.grad)
-            print("grad_fuzz", tag, float(out[f"{tag}/f32/obj"]), len(params))
+                # the same system, one nearest-hit bounce
+                els = getattr(scenes, gen)(ns, np.random.default_rng(seed))
+                if dtype == torch.float64:
+                    for el in els:
+                        el.double()
+                params = scenes.make_all_trainable(els)
+                r = ns.Rays.initialize(rays.pos.to(dtype), rays.dir.to(dtype), dtype=dtype)
+                obj = scenes.fuzz_step_objective(ns, els, r, wp.to(dtype), wd.to(dtype), ws.to(dtype))
+                obj.backward()
+                out[f"{tag}/{dt}/step_obj"] = npy(obj.detach())
+                for name, p in params.items():
+                    out[f"{tag}/{dt}/s/{name}"] = npy(torch.zeros_like(p) if p.grad is None else p.grad)
+            print("grad_fuzz", tag, float(out[f"{tag}/f32/obj"]), float(out[f"{tag}/f32/step_obj"]), len(params))
     np.savez_compressed(os.path.join(OUT, "grad_fuzz.npz"), **out)
 
 

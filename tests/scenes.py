@@ -403,6 +403,23 @@ def fuzz_objective(ns, els, rays, wp, wd, ws):
     return obj
 
 
+def fuzz_step_objective(ns, els, rays, wp, wd, ws):
+    """One nearest-hit bounce (Scene.step) of the same random systems; projection of the stepped rays and of what the
+    sensor recorded, if it was the nearest surface of any ray."""
+    scene = ns.Scene()
+    for el in els:
+        scene.add_element(el)
+    scene._build_index_maps()
+    scene.rays = rays
+    scene.step()
+    r = scene.rays
+    obj = (r.pos * wp).sum() + (r.dir * wd).sum()
+    if els[-1].hitLocs:
+        locs, w, _ = els[-1].getHitsTensors()
+        obj = obj + (locs * ws[: locs.shape[0]] * w[:, None]).sum()
+    return obj
+
+
 # ---------------------------------------------------------------------------------------------
 # ray-source cases (rays/bundle.py)
 # ---------------------------------------------------------------------------------------------

@@ -496,26 +496,28 @@ def test_gradient_of_a_flat_face_curvature(ns):
 
 @pytest.mark.parametrize("gen", ["random_system", "random_system_extra"])
 @pytest.mark.parametrize("seed", range(10))
-def test_gradients_of_random_systems(ns, gen, seed):
+@pytest.mark.parametrize("path", ["sequential", "step"])
+def test_gradients_of_random_systems(ns, gen, seed, path):
     """Every floating-point parameter of a random system trainable (poses with rotations, curvatures, indices,
     thicknesses, focal powers, box sizes, ...): all gradients of a random projection of the traced rays and sensor
     hits against the reference's autograd in float32, judged with its float64 gradients where the two float32
-    evaluations differ."""
+    evaluations differ.  'sequential' traces the system in order, 'step' takes one nearest-hit bounce of it."""
     g = golden("grad_fuzz")
     tag = f"{gen}/{seed}"
-    if not np.isfinite(g[f"{tag}/f32/obj"]):
+    obj_key, grad_key = ("obj", "g") if path == "sequential" else ("step_obj", "s")
+    if not np.isfinite(g[f"{tag}/f32/{obj_key}"]):
         pytest.skip("the reference's own objective is not finite for this system (NaN roots of unbounded surfaces)")
     els = getattr(scenes, gen)(ns, np.random.default_rng(seed))
     params = scenes.make_all_trainable(els)
-    names = [k[len(tag) + 7:] for k in g if k.startswith(f"{tag}/f32/g/")]
+    names = [k[len(tag) + 7:] for k in g if k.startswith(f"{tag}/f32/{grad_key}/")]
     for name in set(params) - set(names):
         # integer-typed in the reference (a pose built from integer literals, the unit slopes of a Linear functor):
         # not trainable there
         params.pop(name).requires_grad_(False)
     rays = ns.Rays.initialize(torch.from_numpy(g[f"{tag}/in_pos"]), torch.from_numpy(g[f"{tag}/in_dir"])).to(DEV)
     wp, wd, ws = (torch.from_numpy(g[f"{tag}/{k}"]).to(DEV) for k in ("wp", "wd", "ws"))
-    obj = scenes.fuzz_objective(ns, els, rays, wp, wd, ws)
-    want_obj, true_obj = float(g[f"{tag}/f32/obj"]), float(g[f"{tag}/f64/obj"])
+    obj = (scenes.fuzz_objective if path == "sequential" else scenes.fuzz_step_objective)(ns, els, rays, wp, wd, ws)
+    want_obj, true_obj = float(g[f"{tag}/f32/{obj_key}"]), float(g[f"{tag}/f64/{obj_key}"])
     got_obj = float(obj.detach())
     # long free paths behind an ideal lens or a paraboloid make the projection a sum of large cancelling terms: the
     # reference's own float32 value is then 1e-4 off its float64 value, and so is ours
@@ -523,13 +525,14 @@ def test_gradients_of_random_systems(ns, gen, seed):
             or abs(got_obj - true_obj) <= 5 * abs(want_obj - true_obj) + 1e-4 * max(1.0, abs(true_obj)))
     obj.backward()
     assert sorted(names) == sorted(params), "every parameter of the reference exists in the package under its name"
-    scale = max(1.0, max(float(np.abs(g[f"{tag}/f64/g/{n}"]).max()) for n in names))
+    scale = max(1.0, max(float(np.abs(g[f"{tag}/f64/{grad_key}/{n}"]).max()) for n in names))
     worst = 0.0
     for name in names:
         p = params[name]
         got = (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu().double().numpy().reshape(-1)
-        want, truth = g[f"{tag}/f32/g/{name}"].reshape(-1).astype(np.float64), g[f"{tag}/f64/g/{name}"].reshape(-1)
+        want = g[f"{tag}/f32/{grad_key}/{name}"].reshape(-1).astype(np.float64)
+        truth = g[f"{tag}/f64/{grad_key}/{name}"].reshape(-1)
         for a, b, c in zip(got, want, truth):
             ok = abs(a - b) <= 2e-4 * scale or abs(a - c) <= 2 * abs(b - c) + 1e-5 * scale
-            assert ok, (tag, name, a, b, c, scale)
+            assert ok, (tag, path, name, a, b, c, scale)
             worst = max(worst, abs(a - c) / scale)
