@@ -54,6 +54,23 @@ def host_value(p) -> np.ndarray:
     return v
 
 
+def prefetch_host(params) -> None:
+    """Bring every device-resident parameter whose host copy is stale to the host in ONE transfer (packing a program
+    reads them one by one; a transfer each would synchronise with the device once per parameter)."""
+    stale = [p for p in params if isinstance(p, torch.Tensor) and p.device.type != "cpu"
+             and (_host_cache.get(id(p)) is None or _host_cache[id(p)][0] != (p.data_ptr(), p._version))]
+    if len(stale) < 2:
+        return
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in stale]).cpu().numpy()
+    at = 0
+    if len(_host_cache) > 4096:
+        _host_cache.clear()
+    for p in stale:
+        n = p.numel()
+        _host_cache[id(p)] = ((p.data_ptr(), p._version), flat[at:at + n].reshape(tuple(p.shape)).copy())
+        at += n
+
+
 def scalar(p) -> np.float32:
     return f32(host_value(p).reshape(-1)[0])
 

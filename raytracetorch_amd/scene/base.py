@@ -101,6 +101,7 @@ class Scene(nn.Module):
         key = (els, tuple((p.data_ptr(), p._version) for p in params))
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
+            P.prefetch_host(params)
             with torch.random.fork_rng(devices=[]):   # keys drawn while packing are replaced below
                 cached = (key, P.compile_elements(self.elements))
             self._prog_cache = cached

@@ -15,7 +15,7 @@ import scenes  # noqa: E402
 
 ns = scenes.namespace_from_package(rta)
 dev = torch.device("cuda", 0)
-n = 16 * 2 ** 20
+n = int(sys.argv[sys.argv.index("--n") + 1]) if "--n" in sys.argv else 16 * 2 ** 20
 lens, sensor = scenes.spot_system(ns, grads=True)
 scene = ns.SequentialScene([lens, sensor])
 if "--device-params" in sys.argv:   # parameters resident on the GPU, as load_scene leaves them
@@ -32,10 +32,15 @@ class Resident(torch.nn.Module):
 loss_fn = ns.SpotSizeLoss(sensor, [Resident()], N_rays=n)
 
 
+opt = torch.optim.SGD([p for p in scene.parameters() if p.requires_grad], lr=0.0) if "--optimizer" in sys.argv else None
+
+
 def step():
     for p in scene.parameters():
         p.grad = None
     loss_fn(scene).backward()
+    if opt is not None:   # a real loop changes the parameters every step: the program is re-packed each time
+        opt.step()
 
 
 for _ in range(3):
