@@ -111,6 +111,36 @@ def cpu_baseline(n, scenes, ns):
                       f"{t * 1e3:.0f} ms per trace"}
 
 
+def cpu_baseline_other(workload, scenes, ns):
+    """The CPU oracle on a bounded sample of the 5-element system (2^20 rays) or the 32-surface nearest-hit step
+    (2^18 rays); None for workloads the oracle has no single call for."""
+    import rtt_oracle as O
+    import raytracetorch_amd.program as P
+    if workload == "system5":
+        n, surfaces, prog, z0 = 2 ** 20, 9, P.compile_elements(scenes.system5(ns)), -30.0
+        run = lambda p, q, w: O.trace_sequential(prog, p, q, w)
+        what = "trace_sequential, 5-element system (9 surfaces)"
+    elif workload == "naive32":
+        n, surfaces, prog, z0 = 2 ** 18, 32, P.compile_elements(scenes.naive32(ns)), -10.0
+        run = lambda p, q, w: O.step_nearest(prog, p, q, w)
+        what = "step_nearest, 32-surface scene (every ray tests every surface)"
+    else:
+        return None
+    pos, d = device_bundle(n, "cpu", 0)
+    pos[2].fill_(z0)
+    pos, d, inten = pos.t().contiguous(), d.t().contiguous(), torch.ones(n)
+    times = []
+    with torch.no_grad():
+        run(pos[:65536], d[:65536], inten[:65536])
+        for _ in range(5):
+            t0 = time.perf_counter()
+            run(pos, d, inten)
+            times.append(time.perf_counter() - t0)
+    t = statistics.median(times)
+    return {"value": n * surfaces / t, "unit": "ray-surface intersections/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"oracle/rtt_oracle.py {what}, {n} rays, median of 5, {t * 1e3:.0f} ms per pass"}
+
+
 def other_workload(a, ns, scenes, dev, rank, world, dist):
     """Configurations 3-5: 5-element system (16 Mi rays), 32-surface nearest-hit step (4 Mi rays), spot-size
     loss forward+backward (singlet + sensor).  Same timing discipline as the headline line."""
@@ -220,7 +250,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
     gpu_ms = statistics.mean(s.elapsed_time(e) for s, e in ev)
     if rank == 0:
         achieved = bytes_per_ray * n / (gpu_ms * 1e-3) / 1e9
-        print(json.dumps({
+        line = {
             "metric": "ray-surface intersections/sec", "value": world * n * surfaces / (elapsed / a.steps),
             "unit": "ray-surface intersections/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -230,7 +260,11 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "kernel_ms": gpu_ms,
                          "algorithmic_bytes_per_launch": bytes_per_ray * n,
-                         "note": "event time spans every kernel of the step, including torch glue"}}), flush=True)
+                         "note": "event time spans every kernel of the step, including torch glue"}}
+        base = None if (world > 1 or a.no_cpu_baseline) else cpu_baseline_other(a.workload, scenes, ns)
+        if base is not None:
+            line["cpu_baseline"] = base
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
