@@ -5,6 +5,8 @@ The reference materialises an [N, S] distance matrix, takes a row-min, then disp
 sub-batches from Python.  Here one kernel per bounce keeps the running (t_min, winner) in
 registers while it loops over the packed surface program, then applies the winner's interaction.
 """
+import operator
+
 import torch
 import torch.nn as nn
 
@@ -12,6 +14,10 @@ from .. import kernels as K
 from .. import program as P
 from ..elements import Element
 from ..rays import Bundle, Rays
+
+
+_DATA_PTR = operator.methodcaller("data_ptr")
+_VERSION = operator.attrgetter("_version")
 
 
 class Scene(nn.Module):
@@ -71,6 +77,10 @@ class Scene(nn.Module):
             n = len(element.shape)
             el += [k] * n
             sf += list(range(n))
+        # simulate() asks for the maps on every call; they change only with the element list
+        if isinstance(old, torch.Tensor) and self.__dict__.get("_index_map_lists") == (el, sf):
+            return
+        self.__dict__["_index_map_lists"] = (el, sf)
         self.register_buffer("map_to_element", torch.tensor(el, dtype=torch.long, device=device))
         self.register_buffer("map_to_surface", torch.tensor(sf, dtype=torch.long, device=device))
         self.total_surfaces = len(el)
@@ -98,7 +108,9 @@ class Scene(nn.Module):
         """Packed surface program of the current elements; re-packed only when an element list entry or a
         parameter (identity, storage or version counter) changed since the last call."""
         els, params = self._element_params()
-        key = (els, tuple((p.data_ptr(), p._version) for p in params))
+        # storage and version counter of every parameter, read by two C-level maps (a generator costs as much as a
+        # small launch for a few dozen parameters)
+        key = (els, tuple(map(_DATA_PTR, params)), tuple(map(_VERSION, params)))
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
             P.prefetch_host(params)
@@ -201,15 +213,18 @@ class Scene(nn.Module):
         bounce in which the sensor was hit, rows in ray order (elements/sensor.py:35-37 under scene/base.py:213-226)."""
         if hit.shape[0] == 0:
             return
-        order = torch.argsort(keys[:, 0].to(torch.int64) * (len(rays) + 1) + keys[:, 1].to(torch.int64))
-        hit, keys = hit[order], keys[order]
-        group, ray = keys[:, 0].to(torch.int64), keys[:, 1].to(torch.int64)
-        starts = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=group.device), group[1:] != group[:-1]])).flatten()
-        bounds = starts.tolist() + [int(group.shape[0])]
-        slot_of = {int(rec["sensor_slot"]): self.elements[int(rec["element_id"])] for rec in prog if int(rec["sensor_slot"]) >= 0}
-        heads = group[starts].tolist()
-        for a, b, g in zip(bounds[:-1], bounds[1:], heads):
-            slot_of[g % P.MAX_SURFACES]._record_hits(hit[a:b, :3], hit[a:b, 3], rays.id[ray[a:b]])
+        # one 64-bit key per row, (bounce, slot) in the high word and the ray in the low one: a single sort gives the
+        # order, and the sorted keys give the groups and the rays without a second gather
+        key, order = torch.sort((keys[:, 0].to(torch.int64) << 32) | keys[:, 1].to(torch.int64))
+        hit = hit[order]
+        ids = rays.id[key & 0xFFFFFFFF]
+        heads, counts = torch.unique_consecutive(key >> 32, return_counts=True)
+        heads, counts = torch.stack([heads, counts]).tolist()
+        slot_of = {k: el for k, el, _ in self._slot_plan(prog)}
+        a = 0
+        for g, c in zip(heads, counts):
+            slot_of[g % P.MAX_SURFACES]._record_hits(hit[a:a + c, :3], hit[a:a + c, 3], ids[a:a + c])
+            a += c
 
     def ray_cast(self, rays):
         """(hit_mask [N], winner_element_ids [N], winner_surf_ids [N]) or None when nothing is hit
