@@ -593,10 +593,31 @@ def gen_physics(ns):
         print("phys", name)
 
 
+def gen_profiles(ns):
+    """The profile scans of tests/test_spherics.py and tests/test_cylindrics.py: Shape.intersectTest of bare lens
+    shapes over a row of parallel rays along x and along y, plus Shape.forward of the first two surfaces."""
+    out = {}
+    for name, shape, extent in scenes.profile_shapes(ns):
+        for axis in (0, 1):
+            rays = scenes.profile_rays(ns, extent, axis)
+            with torch.no_grad():
+                out[f"{name}_t{axis}"] = npy(shape.intersectTest(rays))
+                for j in (0, 1):
+                    t, hg, ng, hl = shape.forward(rays, j)
+                    out[f"{name}_fw{axis}_{j}_t"] = npy(t)
+                    out[f"{name}_fw{axis}_{j}_hit"] = npy(hg)
+                    out[f"{name}_fw{axis}_{j}_n"] = npy(ng)
+                    out[f"{name}_fw{axis}_{j}_local"] = npy(hl)
+        print("profile", name, out[f"{name}_t0"].shape, int(np.isfinite(out[f"{name}_t0"]).sum()), int(np.isfinite(out[f"{name}_t1"]).sum()))
+    np.savez_compressed(os.path.join(OUT, "shape_profiles.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_loader.load()
     ns = scenes.namespace_from_package(ref)
+    if sys.argv[1:] == ["profiles"]:
+        return gen_profiles(ns)
     if sys.argv[1:] == ["bundles"]:
         return gen_bundles(ns)
     if sys.argv[1:] == ["naive_grad"]:
@@ -650,6 +671,7 @@ def main():
     gen_render(ns)
     gen_sensor_groups(ns)
     gen_project(ref)
+    gen_profiles(ns)
 
 
 if __name__ == "__main__":

@@ -69,7 +69,7 @@ class CylSinglet(Cylindric):
                 raise ValueError("|R1| must be larger than Height/2")
             if abs(0.5 * C2) > 1 / height:
                 raise ValueError("|R2| must be larger than Height/2")
-            if self.surfaces[0].sagittalZ(torch.tensor(height / 2)) > self.surfaces[1].sagittalZ(torch.tensor(height / 2)):
+            if self.surfaces[0].sagittalZ(torch.as_tensor(height / 2)) > self.surfaces[1].sagittalZ(torch.as_tensor(height / 2)):
                 raise ValueError("Front and back surfaces intersecting")
 
     @property

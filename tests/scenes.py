@@ -486,3 +486,39 @@ def render_cases(ns):
                                                                              ior_glass=1.7, inked=True, transform=T(ns, 10.0))],
                          dict(cam, position=(-14.0, 10.0, -18.0), look_at=(2.0, 0.0, 10.0), fov_deg=60.0)),
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# bare lens shapes scanned by a row of parallel rays (the constructions of the reference's profile scripts,
+# tests/test_spherics.py:108-146 and tests/test_cylindrics.py:106-122: tensor-valued arguments, a shape rotated by
+# 90 degrees, a box rotated by 45 degrees)
+# ---------------------------------------------------------------------------------------------
+def profile_shapes(ns):
+    t = torch.tensor
+    out = [
+        ("biconvex", ns.Singlet(C1=1 / t(50.0), C2=1 / t(-50.0), D=t(25.0), T=t(10.0)), 30.0),
+        ("biconvex_flipped", ns.Singlet(C1=1 / t(50.0), C2=1 / t(-50.0), D=t(25.0), T=t(10.0),
+                                        transform=ns.RayTransform(rotation=t([0, math.pi / 2, 0]))), 30.0),
+        ("meniscus", ns.Singlet(C1=1 / t(30.0), C2=1 / t(100.0), D=t(20.0), T=t(5.0)), 24.0),
+        ("plano", ns.Singlet(C1=t(0.0), C2=1 / t(-40.0), D=t(25.0), T=t(8.0)), 30.0),
+        ("half_sphere", ns.Singlet(C1=t(0.0), C2=1 / t(-12.6), D=t(25.0), T=t(12.7)), 30.0),
+        ("doublet", ns.Doublet(C1=1 / t(50.0), C2=1 / t(-50.0), C3=1 / t(-200.0), T1=t(10.0), T2=t(5.0), D=t(25.0)), 30.0),
+        ("triplet", ns.Triplet(C1=1 / t(40.0), C2=1 / t(30.0), C3=1 / t(30.0), C4=1 / t(-40.0),
+                               T1=t(8.0), T2=t(4.0), T3=t(8.0), D=t(20.0)), 24.0),
+        ("box45", ns.Box(length=t(1.0), width=t(1.0), height=t(1.0),
+                         transform=ns.RayTransform(rotation=t([0, math.pi / 4, 0]))), 3.0),
+        ("cyl_biconvex", ns.CylSinglet(C1=1 / t(50.0), C2=1 / t(-50.0), width=t(30.0), height=t(20.0), T=t(10.0)), 45.0),
+        ("cyl_plano", ns.CylSinglet(C1=1 / t(30.0), C2=t(0.0), width=t(20.0), height=t(25.0), T=t(8.0)), 37.5),
+        ("cyl_biconcave", ns.CylSinglet(C1=t(1 / -50.0), C2=t(1 / 50.0), width=t(40.0), height=t(20.0), T=t(2.0)), 60.0),
+    ]
+    return out
+
+
+def profile_rays(ns, extent, axis, n=200):
+    """`n` rays along +z from z = -100, spread over `extent` along x (axis 0) or y (axis 1)."""
+    coords = torch.linspace(-extent / 2, extent / 2, n)
+    pos = torch.zeros(n, 3)
+    pos[:, axis] = coords
+    pos[:, 2] = -100.0
+    d = torch.tensor([[0.0, 0.0, 1.0]]).expand(n, 3).contiguous()
+    return ns.Rays.initialize(pos, d)
