@@ -276,3 +276,14 @@ def test_sensor_lists(ns):
         s.getSpotSizeParallel_xy([1, 0])
     s.reset()
     assert s.hitLocs == []
+
+
+def test_names_the_reference_scripts_reach_through_star_imports():
+    """The reference's scripts use names its star imports happen to re-export (`rtt.elements.CylSinglet`,
+    tests/test_cylindrics.py:106; elements/__init__.py:3-6, phys/__init__.py:1)."""
+    import raytracetorch_amd as rtt
+    for name in ("RayTransform", "Singlet", "CylSinglet", "Doublet", "Triplet", "Quadric", "QuadricZY", "Disk", "Rectangle",
+                 "Ellipse", "HalfSphere", "HalfCyl", "BoundedHalfSphere", "RefractSnell", "RefractFresnel", "Block", "Reflect",
+                 "ApertureFilter", "ParaxialDistMat"):
+        assert hasattr(rtt.elements, name), name
+    assert rtt.phys.RayTransform is rtt.geom.RayTransform
