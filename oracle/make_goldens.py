@@ -519,17 +519,15 @@ def gen_paths(ns):
     print("paths", out["step_history"].shape)
 
 
-def gen_render(ns):
+def gen_render(ns, only=None):
     """Renderer.render_3d images (render/camera.py:191-257) with the camera rays that produced them."""
-    for name, (mk_elements, cam_kw) in scenes.render_cases(ns).items():
-        scene = ns.Scene()
-        for el in mk_elements():
-            scene.add_element(el)
-        scene._build_index_maps()
-        cam = ns.Camera(**cam_kw)
+    for name in scenes.render_cases(ns):
+        if only and name not in only:
+            continue
+        scene, cam, rend = scenes.render_setup(ns, name)
         rays = cam.generate_rays()
         with torch.no_grad():
-            img = ns.Renderer(scene).render_3d(cam)
+            img = rend.render_3d(cam)
             t_matrix = torch.cat([el.intersectTest(rays) for el in scene.elements], dim=1)
         np.savez_compressed(os.path.join(OUT, f"render_{name}.npz"), image=npy(img), t_matrix=npy(t_matrix),
                             **rays_arrays(rays, "in_"))
@@ -642,8 +640,8 @@ def main():
         return gen_physics(ns)
     if sys.argv[1:] == ["paths"]:
         return gen_paths(ns)
-    if sys.argv[1:] == ["render"]:
-        return gen_render(ns)
+    if sys.argv[1:2] == ["render"]:
+        return gen_render(ns, only=sys.argv[2:])
     if sys.argv[1:] == ["sensor"]:
         return gen_sensor_groups(ns)
     if sys.argv[1:] == ["project"]:

@@ -485,7 +485,43 @@ def render_cases(ns):
                                   singlet(ns, inked=False), ns.CylSingletLens(c1=0.04, c2=-0.03, height=12.0, width=10.0, t=2.5,
                                                                              ior_glass=1.7, inked=True, transform=T(ns, 10.0))],
                          dict(cam, position=(-14.0, 10.0, -18.0), look_at=(2.0, 0.0, 10.0), fov_deg=60.0)),
+        # the scene of the reference's static render script (tests/render_static.py:23-66): elements assembled by hand
+        # around bare spheres, a blocking box, an orbit camera, a grey background
+        "spheres_and_box": (lambda: hand_built_elements(ns),
+                            dict(position=(-30.0, 0.0, 0.0), look_at=(0.0, 0.0, 0.0), up_vector=(0.0, 1.0, 0.0), fov_deg=40.0,
+                                 width=96, height=96),
+                            dict(camera="OrbitCamera", background_color=(0.9, 0.9, 0.9))),
     }
+
+
+def hand_built_elements(ns):
+    e1 = ns.Element()
+    e1.shape = ns.Sphere(radius=2.0)
+    e1.surface_functions.append(ns.Reflect())
+    e2 = ns.Element()
+    e2.shape = ns.Sphere(radius=2.0, transform=ns.RayTransform(translation=[0, -5, 0]))
+    e2.surface_functions.append(ns.Reflect())
+    e3 = ns.Element()
+    e3.shape = ns.Box(height=7, width=7, length=7, transform=ns.RayTransform(translation=[0, 0, -20]))
+    for _ in range(len(e3.shape)):
+        e3.surface_functions.append(ns.Block())
+    return [e1, e2, e3]
+
+
+def render_setup(ns, name, device=None):
+    """(scene, camera, renderer) of a render case; elements go in through `scene.elements.append` like in the
+    reference's script."""
+    case = render_cases(ns)[name]
+    mk_elements, cam_kw = case[0], case[1]
+    opts = case[2] if len(case) > 2 else {}
+    scene = ns.Scene()
+    for el in mk_elements():
+        scene.elements.append(el)
+    scene._build_index_maps()
+    kw = dict(cam_kw) if device is None else dict(cam_kw, device=device)
+    cam = getattr(ns, opts.get("camera", "Camera"))(**kw)
+    rend = ns.Renderer(scene, background_color=opts["background_color"]) if "background_color" in opts else ns.Renderer(scene)
+    return scene, cam, rend
 
 
 # ---------------------------------------------------------------------------------------------
