@@ -31,8 +31,8 @@ SURFACES_TESTED = 3            # front cap, back cap, edge cylinder
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=64 * 2 ** 20, help="rays per GPU")
     ap.add_argument("--cpu-rays", type=int, default=2 ** 24, help="rays of the CPU-baseline sample (about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -427,25 +427,32 @@ class FusedSpotLossFn(torch.autograd.Function):
         cx, cy = (Sx / W, Sy / W) if centroid else (float(target[0]), float(target[1]))
         mom[3] = 0.0
         _spot_moments(x, y, w, mask, 1, cx, cy, W, mom)
-        loss = allreduce_sum_(mom[3:4].clone(), group)
+        loss = None   # this rank's sum; it travels with the first gradient chunk, one exchange for both
         n, dev = len(rays_in), rays_in.device
         dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
-        if ctx.lit and n:
-            dp = _tangent_program(prog, table, dev)
+        if ctx.lit:   # the same decision on every rank (W is the global sum): the exchanges below pair up
+            dp = _tangent_program(prog, table, dev) if n else None
             for k0, used, padded in _chunks(table):
                 width = padded.shape[2]
-                tan_dev = torch.from_numpy(padded).to(dev)
-                out = torch.zeros(3 * width + 2, dtype=torch.float64, device=dev)
-                with torch.cuda.device(dev):
-                    code = N.lib().rtt_trace_seq_spot_grad_f32(
-                        N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
-                        N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width, int(sensor_slot), cx, cy, W,
-                        N.ptr(out), N.stream_handle(dev))
-                N.check(code, "rtt_trace_seq_spot_grad_f32")
+                out = torch.zeros(3 * width + 3, dtype=torch.float64, device=dev)   # the kernel fills 3 width + 2
+                if n:   # a rank whose shard is empty contributes zeros
+                    tan_dev = torch.from_numpy(padded).to(dev)
+                    with torch.cuda.device(dev):
+                        code = N.lib().rtt_trace_seq_spot_grad_f32(
+                            N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+                            N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(tan_dev), width, int(sensor_slot), cx, cy, W,
+                            N.ptr(out), N.stream_handle(dev))
+                    N.check(code, "rtt_trace_seq_spot_grad_f32")
+                if loss is None:
+                    out[3 * width + 2] = mom[3]
                 allreduce_sum_(out, group)
+                if loss is None:
+                    loss = out[3 * width + 2:3 * width + 3].clone()
                 A, Bx, By = out[:width], out[width:2 * width], out[2 * width:3 * width]
                 d = A - out[3 * width] * Bx - out[3 * width + 1] * By if centroid else A
                 dtheta[k0:k0 + used] = d[:used]
+        if loss is None:   # nothing lit reached the sensor on any rank
+            loss = allreduce_sum_(mom[3:4].clone(), group)
         ctx.dtheta, ctx.thetas = dtheta, thetas
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
