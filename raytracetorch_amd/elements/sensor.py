@@ -33,9 +33,18 @@ class Sensor(Element):
         d = self.__dict__
         d["_locs"], d["_inten"], d["_ids"] = [], [], []
         d["_dense"] = []  # (hit planes [3,N], w [N], mask [N] uint8, id [N]) per visit, not yet compacted
+        d["_dense_bytes"] = 0
+
+    # A dense record holds 17 bytes per *ray*, the reference's list entry 17 bytes per *hit*: a sensor that is neither
+    # read nor reset for many visits (a long stepping loop) compacts its pending records once they pass this size.
+    _DENSE_LIMIT = 4 << 30
 
     def _record_dense(self, hit_planes, w, mask, ids):
         self._dense.append((hit_planes, w, mask, ids))
+        d = self.__dict__
+        d["_dense_bytes"] += 17 * int(w.shape[0])
+        if d["_dense_bytes"] > self._DENSE_LIMIT and len(self._dense) > 1:
+            self._flush()
 
     def _record_hits(self, locs, w, ids):
         """One list entry of already compacted hits (rows in ray order)."""
@@ -53,6 +62,7 @@ class Sensor(Element):
             self._inten.append(w[m])
             self._ids.append(ids[m])
         self.__dict__["_dense"] = []
+        self.__dict__["_dense_bytes"] = 0
 
     @property
     def hitLocs(self):

@@ -287,3 +287,20 @@ def test_names_the_reference_scripts_reach_through_star_imports():
                  "ApertureFilter", "ParaxialDistMat"):
         assert hasattr(rtt.elements, name), name
     assert rtt.phys.RayTransform is rtt.geom.RayTransform
+
+
+def test_sensor_compacts_pending_records_past_its_limit(ns):
+    """Dense per-visit records (17 B per ray) are compacted to the reference's per-hit lists once they pass a size
+    limit, in visit order, so a sensor that is never read or reset does not keep whole bundles alive."""
+    import torch
+    s = ns.Sensor(ns.Disk(1.0))
+    s._DENSE_LIMIT = 17 * 25
+    for v in range(4):
+        hit = torch.arange(30, dtype=torch.float32).reshape(3, 10) + 100 * v
+        mask = torch.zeros(10, dtype=torch.uint8)
+        mask[v::4] = 1
+        s._record_dense(hit, torch.full((10,), float(v + 1)), mask, torch.zeros(10, dtype=torch.int8))
+    assert len(s._dense) < 4 and s._dense_bytes == 17 * 10 * len(s._dense)
+    locs, inten, _ = s.getHitsTensors()
+    assert inten.tolist() == [1.0] * 3 + [2.0] * 3 + [3.0] * 2 + [4.0] * 2
+    assert locs[:3, 0].tolist() == [0.0, 4.0, 8.0] and locs[3, 0].item() == 101.0
