@@ -142,7 +142,7 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     dp = _tangent_program(prog, table, dev)
     fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
     adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
-    for k0, used, padded in _chunks(table):  # kernels exist for 2, 4, 6 and 8 directions
+    for k0, used, padded in _chunks(table):  # kernels exist for 2, 4, 6 and 8 directions; 8 is never the cheapest
         width = padded.shape[2]
         tan_dev = torch.from_numpy(padded).to(dev)
         acc = torch.zeros(width, dtype=torch.float64, device=dev)
@@ -253,7 +253,7 @@ class SimulateNearestFn(torch.autograd.Function):
         dev = rays_in.device
         ctx.group = group
         dp = _tangent_program(prog, table, dev)
-        chunks = list(_chunks(table))
+        chunks = list(_chunks(table, widest=8))
         seeds = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
         if not chunks:   # no trainable scalar: one launch for the values
             chunks = [(0, 0, np.zeros((table.shape[0], TAN_SLOTS, 2), np.float32))]
@@ -373,16 +373,36 @@ class SpotLossFn(torch.autograd.Function):
         return gx * g, gy * g, None, None, None, None
 
 
-def _chunks(table):
+def _widths(n_theta, widest):
+    """Directions per launch.  `widest` = 8: as few launches as possible.  `widest` = 6 (the sequential tangent
+    kernels): the 8-wide instantiation holds one wavefront per SIMD and costs more than two 4-wide launches
+    (16 Mi rays: 0.8 / 0.95 / 1.3 / 2.15 ms for 2 / 4 / 6 / 8 directions), so launches are 6 wide, and a rest of 8
+    goes as 4 + 4."""
+    if widest == 8:
+        return [min(8, n_theta - k) for k in range(0, n_theta, 8)]
+    n, out = n_theta, []
+    while n > 0:
+        if n <= 6:
+            take = n
+        elif n <= 8:
+            take = 4
+        else:
+            take = 6
+        out.append(take)
+        n -= take
+    return out
+
+
+def _chunks(table, widest=6):
     """Yield (k0, width_used, padded [n_surf, 32, width]) with width in {2, 4, 6, 8}."""
-    n_theta = table.shape[2]
-    for k0 in range(0, n_theta, 8):
-        chunk = table[:, :, k0:k0 + 8]
-        used = chunk.shape[2]
+    k0 = 0
+    for used in _widths(table.shape[2], widest):
+        chunk = table[:, :, k0:k0 + used]
         width = max(2, used + (used & 1))
         padded = np.zeros((table.shape[0], TAN_SLOTS, width), dtype=np.float32)
         padded[:, :, :used] = chunk
         yield k0, used, padded
+        k0 += used
 
 
 def _assemble_grads(dtheta, thetas, param_meta, param_ids):

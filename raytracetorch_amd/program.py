@@ -8,6 +8,8 @@ host and everything per-ray happens inside one kernel.  Records are re-packed fr
 ``nn.Parameter`` values on every call; host copies of parameter values are cached by
 ``(data_ptr, _version)`` so unchanged parameters cost no device synchronisation.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -42,32 +44,41 @@ def host_value(p) -> np.ndarray:
         return np.asarray(p, dtype=np.float32)
     if p.device.type == "cpu":
         return p.detach().to(torch.float32).numpy()
-    key = id(p)
-    tag = (p.data_ptr(), p._version)
-    hit = _host_cache.get(key)
-    if hit is not None and hit[0] == tag:
-        return hit[1]
+    hit = _cached(p)
+    if hit is not None:
+        return hit
     v = p.detach().to(device="cpu", dtype=torch.float32).numpy()
+    _remember(p, v)
+    return v
+
+
+def _cached(p):
+    """Host copy of device tensor `p` if one is held for this very tensor object in its current state.  The entry is
+    keyed by id() and therefore also holds a weak reference: a temporary that has been freed can hand its id, its
+    storage address and its version counter (0) to an unrelated new tensor."""
+    hit = _host_cache.get(id(p))
+    if hit is not None and hit[2]() is p and hit[0] == (p.data_ptr(), p._version):
+        return hit[1]
+    return None
+
+
+def _remember(p, v):
     if len(_host_cache) > 4096:
         _host_cache.clear()
-    _host_cache[key] = (tag, v)
-    return v
+    _host_cache[id(p)] = ((p.data_ptr(), p._version), v, weakref.ref(p))
 
 
 def prefetch_host(params) -> None:
     """Bring every device-resident parameter whose host copy is stale to the host in ONE transfer (packing a program
     reads them one by one; a transfer each would synchronise with the device once per parameter)."""
-    stale = [p for p in params if isinstance(p, torch.Tensor) and p.device.type != "cpu"
-             and (_host_cache.get(id(p)) is None or _host_cache[id(p)][0] != (p.data_ptr(), p._version))]
+    stale = [p for p in params if isinstance(p, torch.Tensor) and p.device.type != "cpu" and _cached(p) is None]
     if len(stale) < 2:
         return
     flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in stale]).cpu().numpy()
     at = 0
-    if len(_host_cache) > 4096:
-        _host_cache.clear()
     for p in stale:
         n = p.numel()
-        _host_cache[id(p)] = ((p.data_ptr(), p._version), flat[at:at + n].reshape(tuple(p.shape)).copy())
+        _remember(p, flat[at:at + n].reshape(tuple(p.shape)).copy())
         at += n
 
 

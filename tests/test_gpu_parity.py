@@ -275,3 +275,15 @@ def test_sensor_spot_sizes_per_id(ns):
     sensor.reset()
     with pytest.raises(RuntimeError):
         sensor.getSpotSizeParallel_xy([0])
+
+
+def test_host_copy_cache_ignores_an_entry_left_by_a_freed_tensor():
+    """Host copies of device tensors are cached under id(); a freed temporary can pass its id, storage address and
+    version counter on to a new tensor of another shape, which must not be served the old value."""
+    import weakref
+    p = torch.arange(9.0, device=DEV)
+    other = torch.zeros(1, device=DEV)
+    P._host_cache[id(p)] = ((p.data_ptr(), p._version), np.zeros(1, np.float32), weakref.ref(other))
+    assert P.host_value(p).tolist() == list(range(9))
+    assert P.host_value(p).tolist() == list(range(9))   # now served from its own entry
+    del other

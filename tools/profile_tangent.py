@@ -25,7 +25,11 @@ class Resident(torch.nn.Module):
 
 for label, kw in (("c1 (K=2)", dict(c1_grad=True)), ("c1,c2 (K=2)", dict(c1_grad=True, c2_grad=True)),
                   ("c1,c2,t (K=4)", dict(c1_grad=True, c2_grad=True, t_grad=True)),
-                  ("c1,c2,t,ior (K=6)", dict(c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True))):
+                  ("c1,c2,t,ior (K=6)", dict(c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True)),
+                  ("c1,c2,t,ior,ior_media, pose xy (K=8)", dict(c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True,
+                                                               ior_media_grad=True, pose=True))):
+    if kw.pop("pose", False):
+        kw["transform"] = ns.RayTransform(translation=[0.0, 0.0, 0.0], trans_grad=True, trans_mask=[True, True, False])
     lens = ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5, inked=True, **kw).to(dev)
     sensor = ns.Sensor(ns.Disk(6.0, transform=ns.RayTransform(translation=[0.0, 0.0, 19.0]))).to(dev)
     scene = ns.SequentialScene([lens, sensor])
