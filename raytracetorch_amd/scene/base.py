@@ -89,10 +89,11 @@ class Scene(nn.Module):
         """(ids of the elements, parameters of the scene), re-collected only when the element list changes:
         walking the module tree costs more than launching a small trace."""
         els = tuple(id(el) for el in self.elements)
-        plist = getattr(self, "_param_list", None)
+        plist = self.__dict__.get("_param_list")
         if plist is None or plist[0] != els:
-            plist = (els, list(self.elements.parameters()))
-            self._param_list = plist
+            # the entry keeps the elements themselves: while it exists none of them can be freed and hand its id to a
+            # new element, which would make a changed element list look unchanged
+            plist = self.__dict__["_param_list"] = (els, list(self.elements.parameters()), list(self.elements))
         return plist
 
     def _needs_grad(self, rays=None) -> bool:
@@ -107,7 +108,7 @@ class Scene(nn.Module):
     def _program(self):
         """Packed surface program of the current elements; re-packed only when an element list entry or a
         parameter (identity, storage or version counter) changed since the last call."""
-        els, params = self._element_params()
+        els, params, _ = self._element_params()
         # storage and version counter of every parameter, read by two C-level maps (a generator costs as much as a
         # small launch for a few dozen parameters)
         key = (els, tuple(map(_DATA_PTR, params)), tuple(map(_VERSION, params)))

@@ -304,3 +304,22 @@ def test_sensor_compacts_pending_records_past_its_limit(ns):
     locs, inten, _ = s.getHitsTensors()
     assert inten.tolist() == [1.0] * 3 + [2.0] * 3 + [3.0] * 2 + [4.0] * 2
     assert locs[:3, 0].tolist() == [0.0, 4.0, 8.0] and locs[3, 0].item() == 101.0
+
+
+def test_scene_notices_a_replaced_element_even_if_it_inherits_the_old_id(ns):
+    """The packed program is cached per element list; the cache must hold the elements it was built from, or a freed
+    element could pass its id on to its replacement and the stale program would be served."""
+    import gc
+    scene = ns.Scene()
+    scene.add_element(ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5))
+    first = scene._program().copy()
+    for _ in range(50):   # with the cache holding only ids, some iteration reuses the freed element's address
+        scene.clear_elements()
+        gc.collect()
+        scene.add_element(ns.SingletLens(c1=0.02, c2=-0.03, d=10.0, t=3.0, ior_glass=1.5))
+        assert abs(float(scene._program()[0]["geom"][0]) - 0.02) < 1e-7
+        scene.clear_elements()
+        gc.collect()
+        scene.add_element(ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5))
+        assert abs(float(scene._program()[0]["geom"][0]) - 0.05) < 1e-7
+    assert first.shape == scene._program().shape
