@@ -62,6 +62,10 @@ def _cached(p):
     return None
 
 
+def forget_host_copy(p) -> None:
+    _host_cache.pop(id(p), None)
+
+
 def _remember(p, v):
     if len(_host_cache) > 4096:
         _host_cache.clear()

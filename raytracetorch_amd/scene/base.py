@@ -7,6 +7,7 @@ registers while it loops over the packed surface program, then applies the winne
 """
 import operator
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -107,11 +108,20 @@ class Scene(nn.Module):
 
     def _program(self):
         """Packed surface program of the current elements; re-packed only when an element list entry or a
-        parameter (identity, storage or version counter) changed since the last call."""
+        parameter changed since the last call.  Host-resident parameters are compared by value (numpy views of their
+        storage, so a write through `.data`, which leaves the version counter alone, is seen as well); device-resident
+        ones by storage address and version counter: an in-place write through `p.data` on the device is not seen
+        before `invalidate_program()` — write through `p` under `torch.no_grad()` instead."""
         els, params, _ = self._element_params()
-        # storage and version counter of every parameter, read by two C-level maps (a generator costs as much as a
-        # small launch for a few dozen parameters)
-        key = (els, tuple(map(_DATA_PTR, params)), tuple(map(_VERSION, params)))
+        # read by C-level maps (a generator costs as much as a small launch for a few dozen parameters)
+        ptrs = tuple(map(_DATA_PTR, params))
+        views = self.__dict__.get("_param_views")
+        if views is None or views[0] != (els, ptrs):
+            views = self.__dict__["_param_views"] = (
+                (els, ptrs), [q.detach().reshape(-1).numpy() for q in params if q.device.type == "cpu"],
+                [q for q in params if q.device.type != "cpu"])
+        values = np.concatenate(views[1]).tobytes() if views[1] else b""
+        key = (els, ptrs, values, tuple(map(_VERSION, views[2])))
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
             P.prefetch_host(params)
@@ -127,6 +137,14 @@ class Scene(nn.Module):
             prog = prog.copy()
             prog["seed"][stochastic] = (key & 0xFFFFFFFF, key >> 32)
         return prog
+
+    def invalidate_program(self):
+        """Forget the packed program and every cached host copy of a device-resident parameter of this scene: the next
+        trace reads all parameters again (needed only after in-place writes through `p.data` on the device)."""
+        self.__dict__.pop("_prog_cache", None)
+        self.__dict__.pop("_param_views", None)
+        for q in self._element_params()[1]:
+            P.forget_host_copy(q)
 
     def _slot_plan(self, prog):
         """[(sensor slot, element, intensity function of a Fuzzy filter or None)] in program order, kept while the

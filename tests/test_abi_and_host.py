@@ -323,3 +323,25 @@ def test_scene_notices_a_replaced_element_even_if_it_inherits_the_old_id(ns):
         scene.add_element(ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5))
         assert abs(float(scene._program()[0]["geom"][0]) - 0.05) < 1e-7
     assert first.shape == scene._program().shape
+
+
+def test_program_cache_sees_writes_through_data(ns):
+    """`p.data.fill_(v)` (the reference's documented way to sweep a parameter, project.py:18-23) leaves the version
+    counter of `p` alone; the packed-program cache compares host parameters by value and must see it."""
+    import torch
+    scene = ns.Scene()
+    lens = ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5)
+    scene.add_element(lens)
+    c = lens.shape.surfaces[0].c
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.05) < 1e-7
+    v = c._version
+    c.data.fill_(0.07)
+    assert c._version == v
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.07) < 1e-7
+    with torch.no_grad():
+        c.fill_(0.03)
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.03) < 1e-7
+    c.data = torch.tensor(0.01)
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.01) < 1e-7
+    scene.invalidate_program()
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.01) < 1e-7

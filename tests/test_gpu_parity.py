@@ -287,3 +287,20 @@ def test_host_copy_cache_ignores_an_entry_left_by_a_freed_tensor():
     assert P.host_value(p).tolist() == list(range(9))
     assert P.host_value(p).tolist() == list(range(9))   # now served from its own entry
     del other
+
+
+def test_device_parameters_in_place_writes_and_invalidate_program(ns):
+    """Device-resident parameters are tracked by storage and version counter: a write through the parameter is seen
+    by the next trace, a write through `.data` after `invalidate_program()`."""
+    scene = ns.Scene()
+    lens = ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5)
+    scene.add_element(lens)
+    scene.to(DEV)
+    c = lens.shape.surfaces[0].c
+    assert c.is_cuda and abs(float(scene._program()[0]["geom"][0]) - 0.05) < 1e-7
+    with torch.no_grad():
+        c.fill_(0.03)
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.03) < 1e-7
+    c.data.fill_(0.07)
+    scene.invalidate_program()
+    assert abs(float(scene._program()[0]["geom"][0]) - 0.07) < 1e-7
