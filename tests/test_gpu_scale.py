@@ -364,3 +364,39 @@ def test_more_than_2_to_31_rays(ns):
     assert int((out.intensity > 0).sum()) == n   # the disk of radius 4 passes the 10-wide lens completely
     del rays, out
     torch.cuda.empty_cache()
+
+
+def test_alternating_scenes_without_synchronisation_give_the_same_results_every_time(ns):
+    """Two scenes with the same number of surfaces share one slot of the device-program cache, so alternating them
+    re-uploads the program before every launch while earlier launches may still be queued; results must not depend on
+    that (bitwise), for the sequential trace and for the fused bounce loop with its sensor list."""
+    torch.manual_seed(3)
+    rays0 = scenes.disk_bundle(ns, radius=4.0, z=-30.0, rot=[0.01, 0.02, 0.0]).sample(200001).to("cuda:0")
+    lens_a = [scenes.singlet(ns), ns.Sensor(ns.Disk(8.0, transform=scenes.T(ns, 19.0)))]
+    lens_b = [scenes.singlet(ns, c1=0.03, c2=-0.06, ior_glass=1.6), ns.Sensor(ns.Disk(8.0, transform=scenes.T(ns, 25.0)))]
+    seq = [ns.SequentialScene(lens_a), ns.SequentialScene(lens_b)]
+    naive = []
+    for els in (lens_a, lens_b):
+        sc = ns.Scene()
+        for el in els:
+            sc.add_element(el)
+        sc.Nbounces = 6
+        naive.append(sc)
+    first = {}
+    with torch.no_grad():
+        for it in range(40):
+            k = it & 1
+            for el in (lens_a, lens_b)[k]:
+                if hasattr(el, "reset"):
+                    el.reset()
+            out = seq[k].simulate(rays0.clone())
+            naive[k].rays = rays0.clone()
+            naive[k].simulate()
+            got = (out._pos, out._dir, out.intensity, naive[k].rays._pos, naive[k].rays._dir, naive[k].rays.intensity)
+            if k not in first:
+                first[k] = got
+            else:
+                for a, b in zip(got, first[k]):
+                    assert torch.equal(a, b), f"iteration {it}: result differs from the first run of scene {k}"
+    locs, inten, _ = lens_b[1].getHitsTensors()
+    assert locs.shape[0] > 0 and not torch.equal(first[0][0], first[1][0])
