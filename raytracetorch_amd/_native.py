@@ -118,9 +118,11 @@ def stream_handle(device):
 
 
 class DeviceProgram:
-    """Host records + their device copy.  Uploads are skipped while the bytes are unchanged."""
+    """Host records + their device copy.  Uploads are skipped for the programs used most recently (a few per
+    device, record count and use), so scenes that take turns do not upload before every launch."""
 
     _cache = {}
+    _KEEP = 8
 
     def __init__(self, host: np.ndarray, dev: torch.Tensor):
         self.host = host
@@ -132,12 +134,15 @@ class DeviceProgram:
         prog = np.ascontiguousarray(prog)
         key = (device.index if device.index is not None else torch.cuda.current_device(), prog.shape[0], tag)
         raw = prog.tobytes()
-        hit = cls._cache.get(key)
-        if hit is not None and hit[0] == raw:
-            return hit[1]
+        recent = cls._cache.setdefault(key, {})
+        dp = recent.get(raw)
+        if dp is not None:
+            return dp
         dev = torch.from_numpy(prog.view(np.uint8).reshape(-1).copy()).to(device)
         dp = cls(prog, dev)
-        cls._cache[key] = (raw, dp)
+        if len(recent) >= cls._KEEP:   # drop the oldest copy (dicts keep insertion order)
+            del recent[next(iter(recent))]
+        recent[raw] = dp
         return dp
 
     @property
