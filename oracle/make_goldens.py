@@ -430,14 +430,14 @@ def gen_grad_plano(ns):
     np.savez_compressed(os.path.join(OUT, "grad_plano.npz"), **out)
 
 
-def gen_grad_fuzz(ns):
+def gen_grad_fuzz(ns, seeds=range(10), file_name="grad_fuzz", n=512):
     """Gradients of random systems with every parameter trainable, by the reference's autograd (float32 and
-    float64): the element kinds of both random generators, poses with and without rotation."""
+    float64): the element kinds of both random generators, poses with and without rotation.  `grad_fuzz` holds seeds
+    0-9 with 512 rays, `grad_fuzz_wide` seeds 10-39 with 256 rays."""
     import math
-    n = 512
     out = {}
     for gen in ("random_system", "random_system_extra"):
-        for seed in range(10):
+        for seed in seeds:
             torch.manual_seed(100 + seed)
             rays = scenes.disk_bundle(ns, radius=5.0, z=-15.0, rot=[0.03 * math.sin(seed), 0.02, 0.0]).sample(n)
             wp, wd, ws = torch.randn(n, 3), torch.randn(n, 3), torch.randn(n, 3)
@@ -469,7 +469,7 @@ def gen_grad_fuzz(ns):
                 for name, p in params.items():
                     out[f"{tag}/{dt}/s/{name}"] = npy(torch.zeros_like(p) if p.grad is None else p.grad)
             print("grad_fuzz", tag, float(out[f"{tag}/f32/obj"]), float(out[f"{tag}/f32/step_obj"]), len(params))
-    np.savez_compressed(os.path.join(OUT, "grad_fuzz.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, file_name + ".npz"), **out)
 
 
 def gen_bundles(ns):
@@ -630,6 +630,8 @@ def main():
         return gen_manual_spot(ns)
     if sys.argv[1:] == ["grad_fuzz"]:
         return gen_grad_fuzz(ns)
+    if sys.argv[1:] == ["grad_fuzz_wide"]:
+        return gen_grad_fuzz(ns, seeds=range(10, 40), file_name="grad_fuzz_wide", n=256)
     if sys.argv[1:] == ["plano"]:
         return gen_grad_plano(ns)
     if sys.argv[1:] == ["fuzzy"]:
@@ -663,6 +665,7 @@ def main():
     gen_manual_spot(ns)
     gen_grad_plano(ns)
     gen_grad_fuzz(ns)
+    gen_grad_fuzz(ns, seeds=range(10, 40), file_name="grad_fuzz_wide", n=256)
     gen_bundles(ns)
     gen_physics(ns)
     gen_paths(ns)
