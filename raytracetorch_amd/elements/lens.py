@@ -91,6 +91,25 @@ class SingletLens(Element):
     def T_edge(self):
         return self.shape.T_edge
 
+    @property
+    def P1z(self):
+        """z of the first principal plane in the element frame: front vertex + h1, h1 = -f (n - n0) T c2 / n
+        (elements/lens.py:112-119)."""
+        h1 = -self.f * (self.ior_glass - self.ior_media) * self.T * self.shape.surfaces[1].c / self.ior_glass
+        return self.shape.surfaces[0].z + h1
+
+    @property
+    def P2z(self):
+        """z of the second principal plane: back vertex + h2, h2 = -f (n - n0) T c1 / n (elements/lens.py:121-127)."""
+        h2 = -self.f * (self.ior_glass - self.ior_media) * self.T * self.shape.surfaces[0].c / self.ior_glass
+        return self.shape.surfaces[1].z + h2
+
+    def Bend(self, delta_c):
+        """Declared in the reference to trade c1 against c2 at constant power (elements/lens.py:150-183); there it
+        stops at its first access of `self.shape.C1`, an attribute no lens shape has, so there is no behaviour beyond
+        that AttributeError to reproduce."""
+        raise AttributeError(f"'{type(self.shape).__name__}' object has no attribute 'C1'")
+
 
     def _face_matrices(self, cx_of):
         from .ideal import ParaxialRefractMat
@@ -151,6 +170,10 @@ class DoubletLens(Element):
 
     T1 = property(lambda self: self.shape.T1)
     T2 = property(lambda self: self.shape.T2)
+    # radii as the reference reports them (elements/lens.py:283-294: the sign of the last one flipped)
+    R1 = property(lambda self: 1.0 / self.shape.surfaces[0].c)
+    R2 = property(lambda self: 1.0 / self.shape.surfaces[1].c)
+    R3 = property(lambda self: -1.0 / self.shape.surfaces[2].c)
 
     def getParaxial(self):
         """One refraction matrix per optical surface at its vertex z.  As in the reference, the value handed to the
@@ -184,6 +207,11 @@ class TripletLens(Element):
     T1 = property(lambda self: self.shape.T1)
     T2 = property(lambda self: self.shape.T2)
     T3 = property(lambda self: self.shape.T3)
+    # elements/lens.py:387-398: the last two with the sign flipped
+    R1 = property(lambda self: 1.0 / self.shape.surfaces[0].c)
+    R2 = property(lambda self: 1.0 / self.shape.surfaces[1].c)
+    R3 = property(lambda self: -1.0 / self.shape.surfaces[2].c)
+    R4 = property(lambda self: -1.0 / self.shape.surfaces[3].c)
 
     def getParaxial(self):
         """One refraction matrix per optical surface at its vertex z.  As in the reference, the value handed to the

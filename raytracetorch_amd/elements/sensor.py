@@ -99,6 +99,19 @@ class Sensor(Element):
             locs, inten, ids = locs[m], inten[m], ids[m]
         return locs, inten, ids
 
+    def getSpotSizeID_xy(self, ray_id, target_xy=None, norm_ord=2):
+        """The reference's single-id variant (elements/sensor.py:67-85), kept expression for expression on the
+        compacted hit lists: it weights by the intensities of *all* hits and sums the centroid over both coordinates,
+        so it only evaluates when those shapes happen to broadcast, and fails as the reference does otherwise."""
+        hit_xyz, hit_intensity, hit_id = self.getHitsTensors()
+        chosen = hit_id == ray_id
+        xyz, inten = hit_xyz[chosen], hit_intensity[chosen]
+        total = torch.sum(hit_intensity)
+        if target_xy is None:
+            target_xy = torch.sum(xyz[:, 0:2] * inten[:, None]) / total
+        diff = xyz[:, 0:2] - target_xy[None, :]
+        return torch.sum(hit_intensity * torch.abs(diff) ** norm_ord, dim=0) / total
+
     def _hit_records(self):
         """(x, y, w, mask or None, id) device arrays of every recorded visit, dense or compacted."""
         recs = [(hit[0], hit[1], w, mask, ids) for hit, w, mask, ids in self._dense]

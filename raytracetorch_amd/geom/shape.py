@@ -139,3 +139,8 @@ class Box(CvxPolyhedron):
         self.surfaces.append(_axis_plane([-width / 2, 0.0, 0.0], [0.0, hp, 0.0], w_grad))
         self.surfaces.append(_axis_plane([0.0, height / 2, 0.0], [hp, 0.0, 0.0], h_grad))
         self.surfaces.append(_axis_plane([0.0, -height / 2, 0.0], [-hp, 0.0, 0.0], h_grad))
+
+    # extents between opposite faces (geom/shape.py:147-157)
+    length = property(lambda self: self.surfaces[0].transform.trans[2] - self.surfaces[1].transform.trans[2])
+    width = property(lambda self: self.surfaces[2].transform.trans[0] - self.surfaces[3].transform.trans[0])
+    height = property(lambda self: self.surfaces[4].transform.trans[1] - self.surfaces[5].transform.trans[1])

@@ -120,6 +120,11 @@ class RayTransformNoisy(RayTransform):
     def noisy(self) -> bool:
         return bool((self.trans_scale != 0).any() or (self.rot_scale != 0).any())
 
+    def addNoise(self, N):
+        """Per-ray (translation [N,3], rotation vector [N,3]); without deviations every row is the pose itself
+        (geom/transform.py:195-200)."""
+        return self.trans[None, :].expand(N, 3), self.rot_vec[None, :].expand(N, 3)
+
     def freeze_noise(self, N):
         self.is_frozen = True
 

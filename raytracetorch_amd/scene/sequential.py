@@ -68,6 +68,11 @@ class SequentialScene(Scene):
             system = mats[i + 1] @ (ParaxialDistMat(gaps[i]) @ system)
         return system
 
+    def checkDimensions(self):
+        """Declared in the reference as a check of thicknesses and clearances (scene/sequential.py:64-74); there it
+        stops at its first line, a call of `_getCenterThickness`, which no class defines."""
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '_getCenterThickness'")
+
     def to_base(self):
         """scene/sequential.py:80-105."""
         base = Scene()

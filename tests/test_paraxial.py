@@ -70,3 +70,20 @@ def test_stubs_of_the_reference_stay_stubs(ns):
         rtt.geom.Plane(transform=noisy)._record(0)
     quiet = rtt.geom.RayTransformNoisy(translation=[0.0, 0.0, 1.0])
     assert float(rtt.geom.Plane(transform=quiet)._record(0)["tj"][2]) == 1.0
+
+
+def test_lens_accessors_give_the_reference_values(ns):
+    """Principal planes, radii, thicknesses and box extents (elements/lens.py:112-127, :283-301, :387-408,
+    geom/shape.py:147-157); the numbers are what the reference returns for the same constructions."""
+    import pytest
+    L = ns.SingletLens(c1=1 / 50.0, c2=-1 / 50.0, d=10.0, t=30.0, ior_glass=1.4, ior_media=1.0)
+    D = ns.DoubletLens(0.02, -0.02, -0.005, 25.0, 10.0, 5.0, 1.5, 1.6)
+    T = ns.TripletLens(1 / 40.0, 1 / 30.0, 1 / 30.0, -1 / 40.0, 20.0, 8.0, 4.0, 8.0, 1.5, 1.6, 1.5)
+    B = ns.Box(length=1.0, width=2.0, height=3.0)
+    got = [float(x) for x in (L.P1z, L.P2z, D.R1, D.R2, D.R3, T.R1, T.R2, T.R3, T.R4, T.T1, T.T3, B.length, B.width, B.height)]
+    want = [-3.28125, 3.28125, 50.0, -50.0, 200.0, 40.0, 29.999998, -29.999998, 40.0, 8.0, 8.0, 1.0, 2.0, 3.0]
+    assert got == pytest.approx(want, rel=1e-6)
+    with pytest.raises(AttributeError):
+        L.Bend(0.001)            # the reference stops at `self.shape.C1` as well
+    with pytest.raises(AttributeError):
+        ns.SequentialScene([L]).checkDimensions()
