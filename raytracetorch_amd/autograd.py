@@ -439,6 +439,15 @@ class FusedSpotLossFn(torch.autograd.Function):
     def forward(ctx, rays_in, prog, table, thetas, group, target, sensor_slot, sens, mom, *params):
         hit, w, mask = sens  # dense record of the sensor slot from the forward trace
         x, y = hit[0], hit[1]
+        n, dev = len(rays_in), rays_in.device
+        # everything the tangent launches need that does not depend on the centroid goes to the device now, while it
+        # is still busy with the trace and the first moments: after the synchronisation below only launches remain
+        dp = _tangent_program(prog, table, dev) if n else None
+        staged = []
+        for k0, used, padded in _chunks(table):
+            width = padded.shape[2]
+            staged.append((k0, used, width, torch.from_numpy(padded).to(dev) if n else None,
+                           torch.zeros(3 * width + 3, dtype=torch.float64, device=dev)))   # the kernel fills 3 width + 2
         allreduce_sum_(mom, group)   # `mom` holds this rank's first moments (pass 0, launched by the caller)
         W, Sx, Sy, _ = mom.tolist()
         ctx.lit = W > 0.0
@@ -448,15 +457,10 @@ class FusedSpotLossFn(torch.autograd.Function):
         mom[3] = 0.0
         _spot_moments(x, y, w, mask, 1, cx, cy, W, mom)
         loss = None   # this rank's sum; it travels with the first gradient chunk, one exchange for both
-        n, dev = len(rays_in), rays_in.device
         dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
         if ctx.lit:   # the same decision on every rank (W is the global sum): the exchanges below pair up
-            dp = _tangent_program(prog, table, dev) if n else None
-            for k0, used, padded in _chunks(table):
-                width = padded.shape[2]
-                out = torch.zeros(3 * width + 3, dtype=torch.float64, device=dev)   # the kernel fills 3 width + 2
+            for k0, used, width, tan_dev, out in staged:
                 if n:   # a rank whose shard is empty contributes zeros
-                    tan_dev = torch.from_numpy(padded).to(dev)
                     with torch.cuda.device(dev):
                         code = N.lib().rtt_trace_seq_spot_grad_f32(
                             N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
@@ -487,11 +491,12 @@ class FusedSpotLossFn(torch.autograd.Function):
 _scalars_cache = {}
 
 
-def _cached_scalars(elements):
+def _cached_scalars(elements, params=None):
     """trainable_scalars(elements), re-derived only when the elements or their requires_grad flags change (walking
-    the module trees costs as much as launching a trace)."""
+    the module trees costs as much as launching a trace; a scene passes the parameter list it already keeps)."""
     import weakref
-    params = [p for el in elements for p in el.parameters()]
+    if params is None:
+        params = [p for el in elements for p in el.parameters()]
     key = (tuple(id(el) for el in elements), tuple(id(p) for p in params), tuple(p.requires_grad for p in params))
     hit = _scalars_cache.get(key[0])
     if hit is None or hit[0] != key or any(r() is None for r in hit[1]):
@@ -501,14 +506,14 @@ def _cached_scalars(elements):
     return hit[2]
 
 
-def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None):
+def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None, params=None):
     """Differentiable spot-size loss of a bundle already traced (forward only, no graph) through `prog`;
     `sens` = (hit [3,N], w [N], mask [N]) of the sensor slot, `rays` the *input* bundle of that trace."""
     hit, w, mask = sens
     # first moments right behind the trace; the host work below overlaps both kernels
     mom = torch.zeros(4, device=w.device, dtype=torch.float64)
     _spot_moments(hit[0], hit[1], w, mask, 0, 0.0, 0.0, 1.0, mom)
-    thetas = _cached_scalars(elements)
+    thetas = _cached_scalars(elements, params)
     table = tangent_table(elements, thetas)
     params, seen = [], set()
     for p, _ in thetas:

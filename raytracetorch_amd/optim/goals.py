@@ -127,7 +127,7 @@ class SpotSizeLoss(Goal):
         # the host work of the backward's set-up (parameter list, slot Jacobians) runs while the device traces;
         # "nothing lit reached the sensor" (optim/goals.py:165-167) is read off the first moment, W = 0
         loss = AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
-                                  group=getattr(scene, "grad_group", None))
+                                  group=getattr(scene, "grad_group", None), params=scene._element_params()[1])
         return False if loss is None else loss
 
     def _sensor_records(self):
