@@ -8,6 +8,10 @@ A "step" is one `SequentialScene.simulate` of the singlet scene over one residen
 rays per GPU (default 64 * 2^20): one kernel launch that tests 3 surfaces per ray.  Rays are
 sharded across ranks (each rank owns its own bundle, seeded by rank); the trace has no exchange
 step, so there is no data-path collective and scaling is weak.  Rank 0 prints ONE JSON line.
+
+Started without a launcher (`WORLD_SIZE` unset) and with `--gpus N` > 1, this process only starts N
+fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), waits for them and
+exits with the first non-zero status; it never touches the GPU itself.
 """
 import argparse
 import json
@@ -23,6 +27,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+LIB_PATH = os.environ.get("RTT_HIP_LIB") or os.path.join(ROOT, "raytracetorch_amd", "csrc", "librtt_hip.so")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 BYTES_PER_RAY = 56             # read pos+dir+intensity (28 B) + write the same (28 B), surface-count independent
 SURFACES_TESTED = 3            # front cap, back cap, edge cylinder
@@ -52,6 +57,78 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def child_envs(n_ranks, port, base=None):
+    """Environment of each rank process of a one-node run: what `torch.distributed.run` would set."""
+    base = dict(os.environ if base is None else base)
+    envs = []
+    for r in range(n_ranks):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(n_ranks, argv, timeout=None):
+    """Start one fresh process per rank and wait for all of them.  The caller has not initialised the GPU and this
+    function does not either: the ranks are children (never a replacement of this process), rank 0 inherits stdout
+    and prints the JSON line.  Returns the first non-zero exit status (0 when every rank succeeded); when one rank
+    fails the others are ended, by their own process ids."""
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e)
+             for e in child_envs(n_ranks, free_port())]
+    deadline = None if timeout is None else time.monotonic() + timeout
+    status, pending = 0, list(procs)
+    while pending:
+        time.sleep(0.05)
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+        if pending and (status != 0 or (deadline is not None and time.monotonic() > deadline)):
+            if status == 0:
+                status = 124
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            pending = []
+    return status
+
+
+def max_over_ranks(value, dist, dev):
+    """MAX of a host scalar over all ranks (the timed region ends when the slowest rank does).  Under gloo the
+    value travels as a host tensor: that backend is the rehearsal one (ranks may share a GPU) and needs no device."""
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def lib_sha16():
+    """First 16 hex digits of the SHA-256 of the loaded kernel library: ties a committed counter profile to a build."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def device_bundle(n, device, seed, offset=0, ns=None):
     """CollimatedDisk(radius=4) at z=-30 along +z as [3,N] planes.  On a HIP device the rays come from the
     product's device sampler (Philox stream `seed`, global ray indices offset .. offset+n-1, so the shards of
@@ -76,15 +153,28 @@ def device_bundle(n, device, seed, offset=0, ns=None):
     return pos, d
 
 
-def measured_traffic(n):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (None if the
-    ray count differs from the profiled one)."""
+def measured_traffic(workload, n):
+    """(HBM bytes per launch, note) from the committed rocprofv3 PMC passes of this same command.  The figure is
+    attached only when the profile was taken with the very library that is loaded now (SHA-256 recorded in the
+    file) and with the same ray count; otherwise (None, reason)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_singlet.json")), reverse=True):
+    sha = lib_sha16()
+    reason = f"no committed profile of workload {workload}"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"traffic_{workload}.json")), reverse=True):
         d = json.load(open(f))
-        if d.get("rays_per_gpu") == n:
-            return d["traffic_bytes_per_launch"]
-    return None
+        if d.get("rays_per_gpu") != n:
+            reason = f"{os.path.relpath(f, ROOT)} was taken at {d.get('rays_per_gpu')} rays"
+            continue
+        if d.get("lib_sha16") != sha:
+            reason = f"{os.path.relpath(f, ROOT)} was taken with another build of the library ({d.get('lib_sha16')} != {sha})"
+            continue
+        return d["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, reason
+
+
+def timing_stats(ms):
+    return {"kernel_ms": statistics.mean(ms), "kernel_ms_min": min(ms), "kernel_ms_median": statistics.median(ms),
+            "kernel_ms_max": max(ms)}
 
 
 def cpu_baseline(n, scenes, ns):
@@ -243,22 +333,26 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         s.record(); step(); e.record()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    gpu_ms = statistics.mean(s.elapsed_time(e) for s, e in ev)
+    elapsed = max_over_ranks(elapsed, dist, dev)
+    stats = timing_stats([s.elapsed_time(e) for s, e in ev])
+    gpu_ms = stats["kernel_ms"]
     if rank == 0:
         achieved = bytes_per_ray * n / (gpu_ms * 1e-3) / 1e9
+        traffic, traffic_note = measured_traffic(a.workload, n)
         line = {
             "metric": "ray-surface intersections/sec", "value": world * n * surfaces / (elapsed / a.steps),
             "unit": "ray-surface intersections/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": a.workload, "rays_per_gpu": n, "surfaces": surfaces},
+            "config": {"workload": a.workload, "rays_per_gpu": n, "rays_total": world * n, "surfaces": surfaces,
+                       "ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
+                       "parallelism": (f"rays sharded over {world} GPU(s); "
+                                       + ("sums of a few float64 (spot moments, loss, parameter gradients) all-reduced"
+                                          if a.workload == "spot" else "no data-path collective"))},
             "rays_per_s": world * n / (elapsed / a.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "kernel_ms": gpu_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": kernel, **stats,
                          "algorithmic_bytes_per_launch": bytes_per_ray * n,
                          "note": "event time spans every kernel of the step, including torch glue"}}
         base = None if (world > 1 or a.no_cpu_baseline) else cpu_baseline_other(a.workload, scenes, ns)
@@ -274,9 +368,17 @@ def main():
     if os.environ.get("RTT_BENCH_WATCHDOG"):   # dump every thread's stack and exit if the run takes longer
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RTT_BENCH_WATCHDOG"]), exit=True)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher above us: be the launcher.  Nothing here has touched the GPU (device_count() does not)
+        if a.backend == "nccl" and torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} over RCCL needs {a.gpus} GPUs, this node shows {torch.cuda.device_count()} "
+                             f"(two ranks may share a GPU only with --backend gloo)")
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}: the launcher and the flag must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
     device_index = local_rank % torch.cuda.device_count()   # one rank per GPU on a full node
@@ -346,17 +448,16 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = statistics.mean(s.elapsed_time(e) for s, e in ev)
+    elapsed = max_over_ranks(elapsed, dist, dev)
+    stats = timing_stats([s.elapsed_time(e) for s, e in ev])
+    kernel_ms = stats["kernel_ms"]
     alive = int((out.intensity > 0).sum().item())
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / a.steps
         value = world * n * SURFACES_TESTED / (elapsed / a.steps)
         achieved = BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_note = measured_traffic("singlet", n)
         line = {
             "metric": "ray-surface intersections/sec", "value": value, "unit": "ray-surface intersections/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -365,12 +466,13 @@ def main():
                                    "CollimatedDisk r=4 at z=-30), 3 surfaces tested per ray",
                        "rays_per_gpu": n, "rays_total": world * n, "surfaces": SURFACES_TESTED,
                        "parallelism": f"rays sharded over {world} GPU(s), no data-path collective",
+                       "ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                        "launch": "hip graph replay" if a.graph else "python launcher",
                        "alive_after_trace_rank0": alive},
             "rays_per_s": world * n / (elapsed / a.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n), "kernel": "k_trace_seq",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": BYTES_PER_RAY * n},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": "k_trace_seq", **stats, "algorithmic_bytes_per_launch": BYTES_PER_RAY * n},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_rays, scenes, ns)

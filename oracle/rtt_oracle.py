@@ -306,14 +306,15 @@ def surface_forward(S, p, d):
     return t, hit_g, n, hl
 
 
-def fresnel_uniforms(S, n, u=None):
+def fresnel_uniforms(S, n, u=None, bounce=0):
     """The uniforms of RefractFresnel's choice (phys/std.py:200): given ones (pinning against the
-    reference's torch.rand values), or the Philox words the kernels use for rays 0..n-1 of a call:
-    word 2*(i&1) of block (i >> 1) under key seed + (element_id << 8) + surface_id."""
+    reference's torch.rand values), or the Philox words the kernels use for rays 0..n-1 of a call in bounce
+    `bounce` of a launch: word 2*(i&1) of the block with counter (i >> 1, 0, bounce) under key
+    seed + (element_id << 8) + surface_id."""
     if u is not None:
         return _as(u, S.dtype).reshape(-1, 1)
     key = (S.seed + (S.element_id << 8) + S.surface_id) & (2 ** 64 - 1)
-    ua, _ = philox_uniforms(key, 0, n)
+    ua, _ = philox_uniforms(key, 0, n, word3=bounce)
     return torch.from_numpy(ua).to(S.dtype).reshape(-1, 1)
 
 
@@ -479,12 +480,12 @@ AREA_RECT, AREA_RING = 0, 1
 EMIT_LAMBERT, EMIT_CONE = 0, 1
 
 
-def philox4x32_10(counter, key, word2=0):
+def philox4x32_10(counter, key, word2=0, word3=0):
     """Philox4x32-10 (Salmon et al., SC'11; Random123): counter [M] uint64 placed in words 0-1, word 2 =
-    `word2`, word 3 zero; key uint64.  Returns [M, 4] uint32."""
+    `word2`, word 3 = `word3`; key uint64.  Returns [M, 4] uint32."""
     counter = np.asarray(counter, dtype=np.uint64)
     m32 = np.uint64(0xFFFFFFFF)
-    c = [counter & m32, counter >> np.uint64(32), np.full_like(counter, word2), np.zeros_like(counter)]
+    c = [counter & m32, counter >> np.uint64(32), np.full_like(counter, word2), np.full_like(counter, word3)]
     k0, k1 = np.uint64(int(key) & 0xFFFFFFFF), np.uint64((int(key) >> 32) & 0xFFFFFFFF)
     M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
     for _ in range(10):
@@ -495,11 +496,11 @@ def philox4x32_10(counter, key, word2=0):
     return np.stack(c, axis=1).astype(np.uint32)
 
 
-def philox_uniforms(seed, offset, n):
+def philox_uniforms(seed, offset, n, word3=0):
     """The two unit uniforms of rays offset .. offset+n-1: the pair of rays (2j, 2j+1) shares block j,
     ray 2j takes words (0, 1), ray 2j+1 words (2, 3); u = (x >> 8) * 2^-24."""
     g = np.arange(offset, offset + n, dtype=np.uint64)
-    blocks = philox4x32_10(g >> np.uint64(1), seed)
+    blocks = philox4x32_10(g >> np.uint64(1), seed, word3=word3)
     half = (g & np.uint64(1)).astype(np.int64)
     rows = np.arange(n)
     to_u = lambda x: ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))

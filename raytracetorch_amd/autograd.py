@@ -329,13 +329,31 @@ def simulate_nearest_with_grad(elements, rays, prog, max_bounces, capacity=None,
     return SimulateNearestFn.apply(_detached(rays), prog, table, thetas, max_bounces, capacity, group, rays._pos, rays._dir, *params)
 
 
+class GroupSumFn(torch.autograd.Function):
+    """Sum of a small tensor over the ranks of a group, as a differentiable function: every rank goes on to compute
+    the same global objective from the sum and back-propagates it into its own shard, and the parameter gradients
+    of the shards are added up by the backward of the trace, so the adjoint passes through unchanged."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        return allreduce_sum_(t.detach().clone(), group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class SpotLossFn(torch.autograd.Function):
     """sum_i sqrt(((x_i-cx)^2 + (y_i-cy)^2) w_i / W) over entries with mask and w > 0
     (optim/goals.py:165-183), W and the centroid summed over all ranks of `group` when given.
 
     The value comes from the float64 moment kernels; the backward is the closed form
       dL/dx_i = g_i - (w_i / W) sum_j g_j  (centroid mode),  g_i = (x_i - cx) (w_i / W) / u_i,
-    and w carries no gradient (it is the 0/1 intensity, as in the reference)."""
+    and w carries no gradient (it is the 0/1 intensity, as in the reference).
+
+    Returns (loss, W): W (not differentiable) is the lit weight summed over all ranks, i.e. the one quantity on
+    which every rank can base the same "nothing lit reached the sensor" decision (optim/goals.py:165-167).  Every
+    rank of the group must call this function, also one whose shard recorded nothing: the exchanges pair up."""
 
     @staticmethod
     def forward(ctx, x, y, w, mask, target, group):
@@ -351,10 +369,12 @@ class SpotLossFn(torch.autograd.Function):
         loss = allreduce_sum_(mom[3:4].clone(), group)
         ctx.save_for_backward(xc, yc, wc, mask)
         ctx.consts = (cx, cy, W, target is None, group)
-        return loss.reshape(()).to(torch.float32)
+        wsum = mom[0:1].clone().reshape(())
+        ctx.mark_non_differentiable(wsum)
+        return loss.reshape(()).to(torch.float32), wsum
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gw=None):
         x, y, w, mask = ctx.saved_tensors
         cx, cy, W, centroid, group = ctx.consts
         act = w > 0

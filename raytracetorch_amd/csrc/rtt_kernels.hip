@@ -197,13 +197,13 @@ template <int K> DI Dual<K> div_ieee(Dual<K> a, Dual<K> b) { return a * rcp_(b);
 template <int K> DI float comp(Dual<K> a, int) { return a.v; }
 #undef RTT_DUAL_LOOP
 
-// Philox4x32-10 (Salmon et al. 2011): counter words (c lo, c hi, 0, 0), 64-bit key.
+// Philox4x32-10 (Salmon et al. 2011): counter words (c lo, c hi, word2, word3), 64-bit key.
 struct Philox4 {
   uint32_t x[4];
 };
 
-DI Philox4 philox4x32_10(uint64_t counter, uint64_t key, uint32_t word2 = 0u) {
-  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = word2, c3 = 0u;
+DI Philox4 philox4x32_10(uint64_t counter, uint64_t key, uint32_t word2 = 0u, uint32_t word3 = 0u) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = word2, c3 = word3;
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -806,27 +806,29 @@ DI Forward<T> surface_forward(const RV& S, V3<T> p, V3<T> d, const Frames<T>& f,
   return o;
 }
 
-// The uniform of RefractFresnel's Monte-Carlo choice (phys/std.py:200) for the ray with index r of the call:
-// word 2*(r&1) of the Philox block (r >> 1) under `key`.
+// The uniform of RefractFresnel's Monte-Carlo choice (phys/std.py:200) for the ray with index r of the call in
+// bounce b of the launch: word 2*(r&1) of the Philox block with counter (r >> 1, 0, b) under `key`.  The reference
+// draws fresh numbers at every visit; a ray that meets the same surface again in a later bounce of one launch gets
+// another block through b.
 DI float unit_uniform(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }  // [0, 1), 24 bits
-DI float fresnel_uniform(uint64_t key, uint64_t r, float*) {
-  return unit_uniform(philox4x32_10(r >> 1, key).x[2 * (r & 1)]);
+DI float fresnel_uniform(uint64_t key, uint64_t r, uint32_t b, float*) {
+  return unit_uniform(philox4x32_10(r >> 1, key, 0u, b).x[2 * (r & 1)]);
 }
-DI f2 fresnel_uniform(uint64_t key, uint64_t r, f2*) {
+DI f2 fresnel_uniform(uint64_t key, uint64_t r, uint32_t b, f2*) {
   if ((r & 1) == 0) {  // the usual case: one block serves the lane's two rays
-    const Philox4 b = philox4x32_10(r >> 1, key);
-    return f2{unit_uniform(b.x[0]), unit_uniform(b.x[2])};
+    const Philox4 blk = philox4x32_10(r >> 1, key, 0u, b);
+    return f2{unit_uniform(blk.x[0]), unit_uniform(blk.x[2])};
   }
-  return f2{fresnel_uniform(key, r, (float*)nullptr), fresnel_uniform(key, r + 1, (float*)nullptr)};
+  return f2{fresnel_uniform(key, r, b, (float*)nullptr), fresnel_uniform(key, r + 1, b, (float*)nullptr)};
 }
-template <int K> DI Dual<K> fresnel_uniform(uint64_t key, uint64_t r, Dual<K>*) {
-  return Dual<K>(fresnel_uniform(key, r, (float*)nullptr));
+template <int K> DI Dual<K> fresnel_uniform(uint64_t key, uint64_t r, uint32_t b, Dual<K>*) {
+  return Dual<K>(fresnel_uniform(key, r, b, (float*)nullptr));
 }
 
 // SurfaceFunction.forward(hit_local, dir_global, normal_global) -> (new_dir, imult); `ridx` is the index in
-// the call of the lane's (first) ray, used by the stochastic functor only.
+// the call of the lane's (first) ray and `bounce` the bounce of the launch, used by the stochastic functor only.
 template <class C, class RV, class T>
-DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im, uint64_t ridx) {
+DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im, uint64_t ridx, uint32_t bounce = 0u) {
   const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
   switch (C::pk(S.r)) {
     case RTT_PHYS_BLOCK:  // phys/std.py:243-254
@@ -874,7 +876,7 @@ DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im,
       const T rp = quot(n1ct - n2ci, n1ct + n2ci + 1e-8f);
       const T R = sel(tir, splat<T>(1.0f), 0.5f * (rs * rs + rp * rp));
       const uint64_t key = ((uint64_t)S.r.seed[1] << 32 | S.r.seed[0]) + ((uint64_t)S.r.element_id << 8) + (uint64_t)S.r.surface_id;
-      const T u = fresnel_uniform(key, ridx, (T*)nullptr);
+      const T u = fresnel_uniform(key, ridx, bounce, (T*)nullptr);
       const auto reflect = lt(u, R);
       const T g = sel(ent, mu * ci - ct, ct - mu * ci);  // (mu ci - ct) * (entering ? n : -n)
       const V3<T> refr = scale(mu, d) + scale(g, n);
@@ -982,14 +984,28 @@ DI void store_ray(const RayIO& io, I i, const Ray<T>& r, bool vec = false, int n
   st_(io.inten_out, i, r.I, vec, nv);
 }
 
+// Position in an append list for every lane of the wavefront that offers an entry (`want`): one atomic add per
+// wavefront (the first offering lane adds the number of offering lanes, every lane takes the base plus its rank
+// among them) instead of one same-address atomic per lane, which serialise.  Lanes that do not offer get -1.  May be
+// called under divergence: only the lanes that reach the call take part.
+DI int append_slot(int32_t* count, bool want) {
+  const uint64_t offering = __ballot(want);
+  if (!want) return -1;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int leader = __builtin_ctzll(offering);
+  int base = 0;
+  if (lane == leader) base = atomicAdd(count, (int)__popcll(offering));
+  base = __shfl(base, leader, 64);
+  return base + (int)__popcll(offering & ((1ull << lane) - 1ull));
+}
+
 template <class T, class M, class IX>
 DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, int nv) {
   if (se.app_count) {
 #pragma unroll
     for (int k = 0; k < LaneOf<T>::N; ++k) {
-      if (k >= nv || !mcomp(hit, k)) continue;
-      const int at = atomicAdd(se.app_count, 1);
-      if (at < se.app_cap) {
+      const int at = append_slot(se.app_count, k < nv && mcomp(hit, k));
+      if (at >= 0 && at < se.app_cap) {
         float* h = se.app_hit + 4 * (int64_t)at;
         h[0] = comp(hl.x, k);
         h[1] = comp(hl.y, k);
@@ -1031,7 +1047,7 @@ DI void interact(const RV& S, const Frames<T>& f, T t_raw, M hit, Ray<T>& r, con
   Forward<T> fw = surface_forward<C>(S, r.p, r.d, f, t_raw);
   V3<T> nd;
   T im;
-  apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)(se.index0 + (int64_t)i));
+  apply_physics<C>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)(se.index0 + (int64_t)i), (uint32_t)se.bounce);
   if (sensor) record_sensor(se, S.r.sensor_slot, i, hit, fw.hit_l, r.I, nv);
   if (__all(all_(hit))) {  // every ray of the wavefront hits: plain moves, no selects
     r.p = fw.hit_g;
@@ -1647,9 +1663,9 @@ __global__ void __launch_bounds__(kBlock) k_simulate_nearest_tangent(RayIO io, c
           const Forward<T> fw = surface_forward<CGeneric>(S, r.p, r.d, f, t_raw);
           V3<T> nd;
           T im;
-          apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)i);
+          apply_physics<CGeneric>(S, fw.hit_l, r.d, fw.n_g, nd, im, (uint64_t)i, (uint32_t)b);
           if (S.r.flags & RTT_F_SENSOR) {
-            const int at = atomicAdd(se.app_count, 1);
+            const int at = append_slot(se.app_count, true);
             if (at < se.app_cap) {
               float* h = se.app_hit + 4 * (int64_t)at;
               h[0] = fw.hit_l.x.v;

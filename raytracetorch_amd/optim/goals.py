@@ -20,20 +20,29 @@ class Goal(nn.Module):
     pass
 
 
-def spot_size_from_records(records, target_xy=None, group=None):
+def spot_size_from_records(records, target_xy=None, group=None, device=None):
     """records: iterable of (x [M], y [M], w [M], mask [M] uint8 or None) device tensors.
-    Returns the loss tensor [] (differentiable w.r.t. x and y) or None when no record holds an entry."""
+    Returns the loss tensor [] (differentiable w.r.t. x and y), or None when nothing lit was recorded
+    (optim/goals.py:165-167).  With a rank `group` the sums run over all ranks, "nothing lit" is read off the
+    summed weight (the same decision on every rank), and a rank without any entry still takes part in the
+    exchanges with an empty record on `device`."""
     from ..autograd import SpotLossFn
     records = [r for r in records if r[0].numel() > 0]
     if not records:
-        return None
+        if group is None:
+            return None
+        e = torch.zeros(0, device=device)
+        records = [(e, e.clone(), e.clone(), None)]
     if len(records) == 1:
         x, y, w, m = records[0]
     else:
         ones = lambda r: torch.ones(r[0].numel(), dtype=torch.uint8, device=r[0].device) if r[3] is None else r[3]
         x, y, w = (torch.cat([r[i] for r in records]) for i in range(3))
         m = torch.cat([ones(r) for r in records])
-    return SpotLossFn.apply(x, y, w, m, target_xy, group)
+    loss, wsum = SpotLossFn.apply(x, y, w, m, target_xy, group)
+    if group is not None and not float(wsum) > 0.0:
+        return None
+    return loss
 
 
 class FocalLengthLoss(Goal):
@@ -77,10 +86,19 @@ class SpotTargetLoss(Goal):
                 xy = locs[:, :2]
             else:
                 xy, w = scene.rays.pos[:, :2], scene.rays.intensity
-            if len(w) == 0:
+            group = getattr(scene, "grad_group", None)
+            if group is None and len(w) == 0:
                 continue
-            w_sum = w.sum().clamp(min=1e-12)
-            cx, cy = (xy[:, 0] * w).sum() / w_sum, (xy[:, 1] * w).sum() / w_sum
+            sums = torch.stack([w.sum(), (xy[:, 0] * w).sum(), (xy[:, 1] * w).sum(), w.new_tensor(float(len(w)))])
+            if group is not None:
+                # rays sharded over ranks: the centroid is that of all hits, so the sums (and the number of hits, on
+                # which the skip is decided) run over the group; every rank enters the exchange, also one without a hit
+                from ..autograd import GroupSumFn
+                sums = GroupSumFn.apply(sums, group)
+                if not float(sums[3]) > 0.0:
+                    continue
+            w_sum = sums[0].clamp(min=1e-12)
+            cx, cy = sums[1] / w_sum, sums[2] / w_sum
             t = self.target_xy[min(i, self.target_xy.shape[0] - 1)].to(cx.device)
             losses.append((cx - t[0]) ** 2 + (cy - t[1]) ** 2)
         if not losses:
@@ -164,9 +182,13 @@ class SpotSizeLoss(Goal):
             if not recs:
                 r = scene.rays
                 recs = [(r._pos[0], r._pos[1], r.intensity, None)]
-            if not bool(torch.stack([((r[2] > 0) if r[3] is None else ((r[2] > 0) & r[3].bool())).any() for r in recs]).any()):
+            group = getattr(scene, "grad_group", None)
+            if group is None and not bool(torch.stack([((r[2] > 0) if r[3] is None else ((r[2] > 0) & r[3].bool())).any()
+                                                       for r in recs]).any()):
                 continue  # nothing lit reached the sensor (optim/goals.py:165-167)
-            loss = spot_size_from_records(recs, tgt, group=getattr(scene, "grad_group", None))
+            # with a rank group that decision is taken inside, on the weight summed over all ranks: a rank whose
+            # shard stayed dark must still enter the exchanges of the forward and of the backward
+            loss = spot_size_from_records(recs, tgt, group=group, device=dev)
             if loss is not None:
                 losses.append(loss)
         if not losses:

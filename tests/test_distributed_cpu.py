@@ -68,7 +68,8 @@ def _worker(rank, world, port, n, target, ret):
         x, y, w, mask = _data(n)
         lo, hi = sharding.shard_bounds(n, rank, world)
         xs = x[lo:hi].clone().requires_grad_(True); ys = y[lo:hi].clone().requires_grad_(True)
-        loss = AG.SpotLossFn.apply(xs, ys, w[lo:hi], mask[lo:hi], target, dist.group.WORLD)
+        loss, wsum = AG.SpotLossFn.apply(xs, ys, w[lo:hi], mask[lo:hi], target, dist.group.WORLD)
+        assert float(wsum) == float(((w > 0) & mask.bool()).sum())   # the lit weight of the whole bundle, on every rank
         loss.backward()
         # parameter-gradient vectors are summed the same way
         dtheta = sharding.allreduce_sum_(torch.tensor([float(rank + 1), 2.0], dtype=torch.float64), dist.group.WORLD)
@@ -137,3 +138,43 @@ def test_sensor_hits_gathered_over_ranks(sizes):
         for got, w in zip(ret[rank][:3], want):
             assert got.dtype == w.dtype and torch.equal(got, w)
     assert tuple(want[0].shape) == (sum(sizes), 3)
+
+
+def _dark_shard_worker(rank, world, port, ret):
+    """Non-fused spot-size path (records of an already traced bundle) where rank 1 holds nothing lit, and the
+    centroid goal's group sums where rank 1 holds no hit at all: both ranks must pass through every exchange."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracetorch_amd import autograd as AG
+        from raytracetorch_amd.optim import goals
+        AG._spot_moments = _host_moments
+        x, y, w, mask = _data(4000, seed=3)
+        if rank == 1:
+            w = torch.zeros_like(w)          # every hit of this shard is dark
+        xs = x.clone().requires_grad_(True)
+        loss = goals.spot_size_from_records([(xs, y, w, mask)], None, group=dist.group.WORLD, device="cpu")
+        assert loss is not None
+        loss.backward()
+        empty = torch.zeros(0)
+        lone = goals.spot_size_from_records([] if rank == 1 else [(x, y, w, mask)], None, group=dist.group.WORLD, device="cpu")
+        dark = goals.spot_size_from_records([(x, y, torch.zeros_like(w), mask)], None, group=dist.group.WORLD, device="cpu")
+        s = AG.GroupSumFn.apply(torch.tensor([1.0 + rank, 2.0], requires_grad=True), dist.group.WORLD)
+        ret[rank] = (float(loss), float(xs.grad.abs().sum()), None if lone is None else float(lone), dark, s.tolist(), empty.numel())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_with_a_dark_or_empty_shard_still_takes_part():
+    ret = mp.Manager().dict()
+    mp.spawn(_dark_shard_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    x, y, w, mask = _data(4000, seed=3)
+    want, _, _ = _single_process(x, y, w, mask, None)
+    for rank in range(2):
+        loss, gsum, lone, dark, s, _ = ret[rank]
+        assert abs(loss - want) / want < 1e-6          # rank 1 adds nothing, the loss is rank 0's bundle
+        assert (gsum > 0) == (rank == 0)
+        assert lone is not None and abs(lone - want) / want < 1e-6
+        assert dark is None                              # nothing lit on any rank: skipped on both
+        assert s == [3.0, 4.0]

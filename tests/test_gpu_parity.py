@@ -12,7 +12,10 @@ import torch
 
 import rtt_oracle as O
 import scenes
-from util import INF, PARITY_TOL, assert_parity, golden, pattern_mismatch, rays_from_golden, rel_err
+from functools import partial
+
+import util
+from util import INF, PARITY_TOL, golden, is_hard_case, pattern_mismatch, rays_from_golden, rel_err
 
 import raytracetorch_amd.program as P
 
@@ -33,6 +36,7 @@ def cpu(t):
 
 @pytest.mark.parametrize("name", PRIMS)
 def test_primitive_forward(ns, name):
+    assert_parity = partial(util.assert_parity, hard=is_hard_case(name))
     g = golden("prim_" + name)
     cases = dict(scenes.primitive_cases(ns)); cases.update(scenes.kat_rays(ns))
     surf = cases[name][0]()
@@ -56,6 +60,7 @@ def test_primitive_forward(ns, name):
 
 @pytest.mark.parametrize("name", SEQ)
 def test_sequential_trace(ns, name):
+    assert_parity = partial(util.assert_parity, hard=is_hard_case(name))
     g = golden("seq_" + name)
     elements = scenes.sequential_cases(ns)[name][0]()
     prog = P.compile_elements(elements)

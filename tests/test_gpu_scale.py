@@ -41,8 +41,9 @@ def check_against_oracle(prog, rays_in, rays_out, idx, what):
     o64 = O.trace_sequential(prog, p, d, I, dtype=torch.float64)
     got_I = rays_out.intensity[idx].cpu().numpy()
     assert np.array_equal(got_I > 0, o32["intensity"].numpy() > 0), what
-    assert_parity(rays_out.pos[idx].cpu().numpy(), o32["pos"].numpy(), o64["pos"].numpy(), what=what + " pos")
-    assert_parity(rays_out.dir[idx].cpu().numpy(), o32["dir"].numpy(), o64["dir"].numpy(), what=what + " dir")
+    # the benchmark configurations at their full size: the plain tolerance decides, no float64 tie-break
+    assert_parity(rays_out.pos[idx].cpu().numpy(), o32["pos"].numpy(), o64["pos"].numpy(), what=what + " pos", hard=True)
+    assert_parity(rays_out.dir[idx].cpu().numpy(), o32["dir"].numpy(), o64["dir"].numpy(), what=what + " dir", hard=True)
 
 
 @pytest.mark.parametrize("n", [2 ** 20, 64 * 2 ** 20])
@@ -135,8 +136,8 @@ def test_naive32_full_size(ns):
     o = O.step_nearest(prog, p, d, I)
     o64 = O.step_nearest(prog, p, d, I, dtype=torch.float64)
     same = ok & (o64["winner"].numpy() == o["winner"].numpy())
-    assert_parity(rays.pos[idx].cpu().numpy()[same], o["pos"].numpy()[same], o64["pos"].numpy()[same], what="naive step pos")
-    assert_parity(rays.dir[idx].cpu().numpy()[same], o["dir"].numpy()[same], o64["dir"].numpy()[same], what="naive step dir")
+    assert_parity(rays.pos[idx].cpu().numpy()[same], o["pos"].numpy()[same], o64["pos"].numpy()[same], what="naive step pos", hard=True)
+    assert_parity(rays.dir[idx].cpu().numpy()[same], o["dir"].numpy()[same], o64["dir"].numpy()[same], what="naive step dir", hard=True)
     assert np.array_equal((rays.intensity[idx].cpu().numpy() > 0)[same], (o["intensity"].numpy() > 0)[same])
     # a second bounce runs and leaves rays that missed everything untouched
     miss = ~hit

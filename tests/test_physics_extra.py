@@ -107,6 +107,44 @@ def test_fresnel_lens_trace_matches_oracle(ns):
 
 
 @pytest.mark.gpu
+def test_fresnel_draws_differ_between_bounces_of_one_launch(ns):
+    """A ray that meets the same Fresnel surface again in a later bounce of the fused bounce loop must get a new
+    uniform there, as the reference's per-visit torch.rand gives it (phys/std.py:200).  The path front face
+    (transmitted) -> back face (reflected) -> front face from inside visits the front face twice; a ray that went
+    through it at bounce 0 drew u >= R, so with the same u again it could practically never reflect at bounce 2,
+    and rays with four or more interactions would (almost) not exist.  The lens is small (|coordinates| < 0.5), where
+    float32 rays do not re-hit the surface they stand on.  The step loop draws a new key per launch and is the
+    yardstick: both must show the same share of such rays."""
+    import raytracetorch_amd.kernels as K
+    n = 1 << 20
+    lens = ns.SingletLens(c1=0.5, c2=-0.5, d=0.4, t=0.1, ior_glass=1.5, ior_media=1.0, fresnel=True, inked=True)
+    scene = ns.Scene()
+    scene.add_element(lens)
+    src = ns.CollimatedDisk(radius=0.1, ray_id=0, device=DEV,
+                            transform=ns.RayTransformBundle(translation=[0.0, 0.0, -0.3]).to(DEV)).sample(n, seed=3)
+    torch.manual_seed(1)
+    fused = src.clone()
+    bounces, _ = K.simulate_nearest(fused, scene._program(), 8, want_bounces=True)
+    deep_fused = int((bounces >= 4).sum())
+    # the same scene, one launch per bounce
+    torch.manual_seed(2)
+    scene.rays = src.clone()
+    count = torch.zeros(n, dtype=torch.int32, device=DEV)
+    for _ in range(8):
+        before = scene.rays._pos.clone()
+        scene.step()
+        count += (scene.rays._pos != before).any(0).to(torch.int32)
+    deep_steps = int((count >= 4).sum())
+    assert deep_steps > 500                      # about n (1 - R) R R with R ~ 0.04
+    sigma = (deep_steps + deep_fused) ** 0.5
+    assert abs(deep_fused - deep_steps) < 6 * sigma, (deep_fused, deep_steps)
+    # and the two interaction-count histograms as a whole
+    for k in range(1, 6):
+        a, b = int((bounces == k).sum()), int((count == k).sum())
+        assert abs(a - b) < 6 * (a + b + 1) ** 0.5 + 1e-4 * n, (k, a, b)
+
+
+@pytest.mark.gpu
 def test_ideal_thin_lens_known_answers(ns):
     """tests/test_ideal.py:55-107 of the reference: a point 2f in front of an ideal thin lens images 2f behind
     it with magnification -1 (tolerance of the reference's test: 0.1 on the mean, 1e-3 on the spread)."""

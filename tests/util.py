@@ -39,7 +39,22 @@ def rel_err(a, b):
 PARITY_TOL = 1e-5
 
 
-def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what=""):
+# Every parity check that could not be settled by the plain tolerance and went to the float64 tie-break, by the
+# name of the check: {"worst": deviation from the reference, "ours": worst deviation from float64, "ref": the
+# reference's own}.  tests/test_zy_parity_accounting.py compares the names with the committed allow-list, so the
+# set cannot grow unnoticed; conftest.py writes the list to gpurun_out/parity_tie_breaks.json at session end.
+TIE_BREAKS = {}
+
+# The configurations the benchmark contract names (plane, singlet, 5-element system): their checks pass the plain
+# tolerance or fail, a float64 evaluation is never consulted.
+HARD_CASES = ("plane_c1", "singlet", "system5")
+
+
+def is_hard_case(name):
+    return name in HARD_CASES
+
+
+def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what="", hard=False):
     """`got` agrees with the reference's float32 result `ref` within `tol` on every ray.
 
     Two correct float32 evaluations can differ by more than that on ill-conditioned rays: the
@@ -47,13 +62,16 @@ def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what=""):
     under a cancelling `-B - sqrt(disc)` is amplified a hundredfold (a paraxial ray on a paraboloid
     shows 3e-5 in t).  When a float64 evaluation `truth` of the same formulas is supplied, such a
     case is accepted if `got` is no further from `truth` than twice the reference's own deviation
-    from it, both at the worst ray and at the 99th percentile."""
+    from it, both at the worst ray and at the 99th percentile; the case is then entered in TIE_BREAKS.
+    `hard` ignores `truth`: the plain tolerance decides."""
     e = ray_err(got, ref)
     if e.size == 0 or np.isnan(e).all():
         return
     worst = float(np.nanmax(e))
     if worst < tol:
         return
+    if hard:
+        truth = None
     assert truth is not None, f"{what}: deviates from the reference by {worst:.3g} (> {tol})"
     frac = float(np.nanmean(e >= tol))
     eg, er = ray_err(got, truth), ray_err(ref, truth)
@@ -63,6 +81,7 @@ def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what=""):
     assert wg <= 2.0 * wr + 1e-6 and pg <= 2.0 * pr + 1e-6, (
         f"{what}: {frac:.2%} of rays deviate from the reference by more than {tol} (worst {worst:.3g}); "
         f"vs float64 worst/p99: ours {wg:.3g}/{pg:.3g}, reference {wr:.3g}/{pr:.3g}")
+    TIE_BREAKS[what] = {"worst": worst, "ours": wg, "ref": wr, "ours_p99": pg, "ref_p99": pr, "frac": frac, "tol": tol}
 
 
 def pattern_mismatch(a, b):
