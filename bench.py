@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--tune-blocks", type=int, default=0, help="override the grid cap for experiments")
     ap.add_argument("--tune-reduce-blocks", type=int, default=0, help="override the grid of the reducing kernels (experiment)")
     ap.add_argument("--tune-cull", type=int, default=-1, help="0: nearest-hit kernels test every surface (experiment)")
+    ap.add_argument("--tune-adjoint-lane", type=int, default=0, help="rays per lane of the reverse-mode backward: 1, 2, 0 = automatic")
     return ap.parse_args()
 
 
@@ -306,7 +307,9 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         if dist is not None:
             scene.grad_group = dist.group.WORLD
         surfaces = 4
-        kernel = "k_trace_seq + k_spot_moments + k_trace_seq_tangent<6, spot>"
+        kernel = ("k_trace_seq + k_spot_moments x2 + k_trace_seq_adjoint + k_sum_partials"
+                  if os.environ.get("RTT_BACKWARD", "adjoint") == "adjoint" else
+                  "k_trace_seq + k_spot_moments x2 + k_trace_seq_tangent<6, spot>")
 
         class _Resident(torch.nn.Module):
             """Bundle stand-in for SpotSizeLoss: hands out the resident synthetic rays."""
@@ -407,6 +410,8 @@ def main():
         _native.check(_native.lib().rtt_tune(5, a.tune_reduce_blocks), "rtt_tune")
     if a.tune_cull >= 0:
         _native.check(_native.lib().rtt_tune(3, a.tune_cull), "rtt_tune")
+    if a.tune_adjoint_lane:
+        _native.check(_native.lib().rtt_tune(6, a.tune_adjoint_lane), "rtt_tune")
 
     if a.workload != "singlet":
         return other_workload(a, ns, scenes, dev, rank, world, dist)

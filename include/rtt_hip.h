@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTT_ABI_VERSION 3
+#define RTT_ABI_VERSION 4
 #define RTT_MAX_SURFACES 64 /* upper bound on n_surf accepted by every entry point */
 
 /* error codes */
@@ -79,8 +79,9 @@ enum {
                             phys_R, or Rj when RTT_F_PHYS_ROT_SURF is set (elements/ideal.py:47-55) */
   RTT_PHYS_FRESNEL = 6   /* std.py:148-219: Snell refraction or mirror reflection, chosen per ray by
                             u < R(Fresnel); phys as RTT_PHYS_SNELL.  u is word 2*(i&1) of the Philox4x32-10
-                            block with counter (i >> 1) and key seed + surface position in the program,
-                            u = (x >> 8) * 2^-24, i = index of the ray in the call */
+                            block with counter (i >> 1, 0, b) and key seed + surface position in the program,
+                            u = (x >> 8) * 2^-24, i = index of the ray in the call, b = bounce of the launch (0 in
+                            the sequential trace), so that a ray meeting the surface again draws a new number */
 };
 
 /* flags */
@@ -166,6 +167,33 @@ int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const 
                                 const float* tan_dev, int n_theta, int sensor_slot, double cx, double cy, double wsum,
                                 double* out, void* stream);
 
+/* ---- reverse-mode backward of the sequential trace (the same autograd semantics as above: scene/sequential.py:12-36
+ * under optim/goals.py:144-187 and tests/test_optimize_singlet.py:66-116 of the reference; gradient masks and shared
+ * Parameters, geom/transform.py:29-46 and elements/lens.py:42-56, are the caller's contraction).
+ * Every ray is re-traced once keeping its state in front of each surface it hits, then the adjoint of the ray state is
+ * swept back through the surfaces.  The cost does not depend on the number of trainable scalars: the kernel returns the
+ * adjoints of the record slots themselves (slot numbering as in the tangent table: Rs 0-8, ts 9-11, Rj 12-20, tj 21-23,
+ * geom 24-27, phys 28-31), summed over the rays, and the caller contracts them with d(slot)/d(parameter).
+ *   slot_mask  host array [n_surf]: bit j of slot_mask[s] asks for the adjoint of slot j of surface s (NULL: none);
+ *   slot_adj   device array of one float64 per set bit, ordered by surface and, within a surface, by slot; overwritten;
+ *   adj_pos, adj_dir, adj_sens   upstream adjoints as for rtt_trace_seq_tangent_f32 (each nullable);
+ *   spot_slot >= 0 instead forms the upstream adjoint of the spot-size loss in the kernel, on the hits of that sensor
+ *     slot with intensity w > 0:  g = (x-cx, y-cy)(w/W)/sqrt(((x-cx)^2+(y-cy)^2) w/W) - (w/W)(Gx, Gy), W = wsum, and
+ *     (Gx, Gy) read from the two float64 at spot_g (device memory: the sums of the first term over all rays, e.g.
+ *     out[4..5] of rtt_spot_moments_f32 pass 2, reduced over ranks) or taken as zero when spot_g is NULL (fixed target);
+ *   ray_adj    (nullable) [6][ld_ray]: adjoint of the input rays, as rtt_trace_seq_ray_adjoint_f32 returns it;
+ *   workspace  device scratch for the per-block sums, rtt_trace_seq_adjoint_workspace_bytes(number of set bits) bytes.
+ * Limits: rtt_trace_seq_adjoint_max_slots(n_surf) set bits per call (the per-surface ray states and the per-lane sums
+ * live in the 160 KB of LDS of a compute unit); RTT_E_SIZE beyond that — split the mask over several calls, or use the
+ * tangent entry points.  prog_host is required. */
+int rtt_trace_seq_adjoint_max_slots(int n_surf);
+int64_t rtt_trace_seq_adjoint_workspace_bytes(int n_slots);
+int rtt_trace_seq_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
+                              const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
+                              int spot_slot, double cx, double cy, double wsum, const double* spot_g, float* ray_adj,
+                              int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
  * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
  * tmin[i] = that t.  Either output may be NULL. */
@@ -249,6 +277,8 @@ int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float*
 /* ---- spot-size moments: SpotSizeLoss.forward (optim/goals.py:165-183) -------------------------
  * pass 0: out[0..2] += sum w, sum w x, sum w y over entries with mask != 0 and w > 0.
  * pass 1: out[3] += sum sqrt(((x-cx)^2 + (y-cy)^2) * (w / wsum)) over the same entries.
+ * pass 2: pass 1 and out[4..5] += sum g, g = (x-cx, y-cy)(w/wsum)/sqrt(((x-cx)^2+(y-cy)^2) w/wsum): what the centroid
+ *         term of the loss gradient needs (rtt_trace_seq_adjoint_f32, spot_g); `out` then holds 6 doubles.
  * `out` is 4 doubles in device memory that the caller zeroes before pass 0. */
 int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n,
                          int pass, double cx, double cy, double wsum, double* out, void* stream);
@@ -315,7 +345,9 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * whose bounding sphere lies beyond the nearest hit found so far (same results);
  * key 4: number of blocks of rtt_spot_moments_f32 (default 768: every block ends in float64 atomics on the same
  * few addresses, which serialise at about 12 ns each, so more blocks cost more than they stream);
- * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048.
+ * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048;
+ * key 6: rays per lane of rtt_trace_seq_adjoint_f32: 0 (default) two when the LDS need allows two blocks per compute
+ * unit, else one; 1 or 2 force the choice.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

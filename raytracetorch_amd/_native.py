@@ -31,6 +31,8 @@ _SIGNATURES = {
                                   _vp, _vp],
     "rtt_trace_seq_spot_grad_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _int, _int, _dbl, _dbl, _dbl,
                                     _vp, _vp],
+    "rtt_trace_seq_adjoint_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
+                                  _int, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
     "rtt_ray_cast_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp],
     "rtt_step_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                              _vp, _vp, _vp, _vp, _i64, _vp],
@@ -49,7 +51,8 @@ _SIGNATURES = {
     "rtt_render_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp],
     "rtt_sample_bundle_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
 }
-EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune")
+EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune",
+                                "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes")
 
 
 class RttSource(ctypes.Structure):
@@ -87,6 +90,10 @@ def lib():
     L.rtt_tune.argtypes = [_int, _int]
     L.rtt_tune.restype = _int
     L.rtt_surface_record_bytes.restype = _int
+    L.rtt_trace_seq_adjoint_max_slots.argtypes = [_int]
+    L.rtt_trace_seq_adjoint_max_slots.restype = _int
+    L.rtt_trace_seq_adjoint_workspace_bytes.argtypes = [_int]
+    L.rtt_trace_seq_adjoint_workspace_bytes.restype = _i64
     if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
         raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")
     _lib = L

@@ -3,15 +3,22 @@ with respect to the scene's trainable parameters.
 
 The reference gets these by letting torch autograd record every elementwise op of the trace
 (hundreds of saved [N] tensors per surface visit).  Here the trace is one kernel, so the backward is
-one kernel as well: ``rtt_trace_seq_tangent_f32`` re-traces every ray with dual numbers — forward
-mode over up to 8 parameter directions at a time — and contracts the per-ray tangents with the
-upstream adjoints on the fly.  Nothing per-ray is saved between forward and backward except the
-input bundle itself.
+one kernel as well.  The sequential trace uses reverse mode (``rtt_trace_seq_adjoint_f32``): every ray is
+re-traced once, the adjoint of its state is swept back through the surfaces it hit, and the kernel
+returns the adjoints of the record slots summed over the rays — its cost does not depend on the number
+of trainable scalars, and the adjoint that arrives at the start of a ray is the gradient with respect to
+the input rays.  The forward-mode kernels (``rtt_trace_seq_tangent_f32``: dual numbers over up to 8
+parameter directions per launch, contracted with the upstream adjoints on the fly) remain for programs
+whose per-surface states do not fit the LDS of a compute unit, for the nearest-hit bounce loop, and as an
+independent check (``RTT_BACKWARD=tangent``).  Nothing per-ray is saved between forward and backward
+except the input bundle itself.
 
 Host side, the derivative of each packed record slot with respect to each trainable scalar
 (d(c(1+k))/dc, dR/d(rot_vec), d(n_out/n_in)/d(n_in), shared Parameters, ...) is obtained by building
 the differentiable slots as tiny torch expressions (`_diff_slots`) and asking torch for their Jacobian.
 """
+import ctypes
+import os
 from typing import List, Tuple
 
 import numpy as np
@@ -156,6 +163,65 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
     return out
 
 
+def backward_mode() -> str:
+    """"adjoint" (reverse mode, the default) or "tangent" (forward mode) for the sequential trace."""
+    mode = os.environ.get("RTT_BACKWARD", "adjoint")
+    if mode not in ("adjoint", "tangent"):
+        raise ValueError("RTT_BACKWARD must be 'adjoint' or 'tangent'")
+    return mode
+
+
+def _slot_pairs(table):
+    """(surface, slot) of every record slot that moves with some trainable scalar, in the kernel's accumulator
+    order (by surface, then by slot)."""
+    return np.argwhere(np.any(table != 0.0, axis=2))
+
+
+def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=None, want_ray_adj=False, spot=None):
+    """Reverse-mode backward of the sequential trace: (d objective / d theta [n_theta] float64 on the device,
+    [6, N] adjoint of the input rays or None).  The objective is given by the upstream adjoints of the output planes
+    and of the sensor records, or, with `spot` = (sensor slot, cx, cy, W, device tensor of (Gx, Gy) or None), by the
+    spot-size loss whose adjoint the kernel forms itself.  Returns None when the program is too long for the
+    kernel's LDS budget (the caller then uses the forward-mode kernels)."""
+    n, dev = len(rays_in), rays_in.device
+    n_surf, n_theta = table.shape[0], table.shape[2]
+    lib = N.lib()
+    budget = lib.rtt_trace_seq_adjoint_max_slots(n_surf)
+    pairs = _slot_pairs(table)
+    if budget == 0 and (len(pairs) or want_ray_adj):
+        return None
+    dtheta = torch.zeros(n_theta, dtype=torch.float64, device=dev)
+    ray_adj = torch.zeros((6, n), dtype=torch.float32, device=dev) if want_ray_adj else None
+    if n == 0:
+        return dtheta, ray_adj
+    dp = N.DeviceProgram.upload(prog, dev)
+    fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
+    adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
+    slot, cx, cy, wsum, g_dev = (-1, 0.0, 0.0, 1.0, None) if spot is None else spot
+    chunks = [pairs[k:k + budget] for k in range(0, len(pairs), budget)] if len(pairs) else [pairs]
+    for c, chunk in enumerate(chunks):
+        masks = np.zeros(n_surf, dtype=np.uint32)
+        for sfc, slt in chunk:
+            masks[sfc] |= np.uint32(1) << np.uint32(slt)
+        n_acc = len(chunk)
+        slot_adj = torch.empty(max(n_acc, 1), dtype=torch.float64, device=dev)
+        ws_bytes = int(lib.rtt_trace_seq_adjoint_workspace_bytes(n_acc))
+        ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+        first = c == 0
+        with torch.cuda.device(dev):
+            code = lib.rtt_trace_seq_adjoint_f32(
+                N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n, masks.ctypes.data,
+                N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+                int(slot), float(cx), float(cy), float(wsum), N.ptr(g_dev),
+                N.ptr(ray_adj) if first else 0, n, N.ptr(slot_adj), N.ptr(ws), ws_bytes, N.stream_handle(dev))
+        N.check(code, "rtt_trace_seq_adjoint_f32")
+        if n_acc:
+            rows = torch.from_numpy(table[chunk[:, 0], chunk[:, 1], :].astype(np.float64)).to(dev, non_blocking=True)
+            dtheta += slot_adj[:n_acc] @ rows
+    return dtheta, ray_adj
+
+
 def _ray_adjoint(rays_in, prog, adj_pos, adj_dir, adj_sens):
     """[6, N]: d(objective)/d(pos x, y, z, dir x, y, z of every input ray) of a sequential trace."""
     n, dev = len(rays_in), rays_in.device
@@ -203,11 +269,18 @@ class TraceSeqFn(torch.autograd.Function):
     def backward(ctx, g_pos, g_dir, _gi, g_sens, _gw, _gm):
         if g_sens is not None and g_sens.numel() == 0:
             g_sens = None
-        dtheta = _tangent_contract(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens)
-        allreduce_sum_(dtheta, ctx.group)
+        want_rays = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        swept = None
+        if backward_mode() == "adjoint":   # one reverse sweep yields both kinds of gradient
+            swept = _adjoint_sweep(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens, want_ray_adj=want_rays)
         g_pos_in = g_dir_in = None
-        if ctx.needs_input_grad[5] or ctx.needs_input_grad[6]:
-            adj = _ray_adjoint(ctx.rays_in, ctx.prog, g_pos, g_dir, g_sens)
+        if swept is not None:
+            dtheta, adj = swept
+        else:
+            dtheta = _tangent_contract(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens)
+            adj = _ray_adjoint(ctx.rays_in, ctx.prog, g_pos, g_dir, g_sens) if want_rays else None
+        allreduce_sum_(dtheta, ctx.group)
+        if adj is not None:
             g_pos_in, g_dir_in = adj[:3], adj[3:]
         grads = _assemble_grads(dtheta, ctx.thetas, ctx.param_meta, ctx.param_ids)
         return (None, None, None, None, None, g_pos_in, g_dir_in, *grads)
@@ -460,6 +533,27 @@ class FusedSpotLossFn(torch.autograd.Function):
         hit, w, mask = sens  # dense record of the sensor slot from the forward trace
         x, y = hit[0], hit[1]
         n, dev = len(rays_in), rays_in.device
+        ctx.thetas = thetas
+        ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
+        ctx.param_ids = [id(p) for p in params]
+        if backward_mode() == "adjoint" and N.lib().rtt_trace_seq_adjoint_max_slots(int(table.shape[0])) > 0:
+            # reverse mode: first moments -> centroid; second pass -> loss and the centroid term (Gx, Gy), which stay
+            # on the device; one reverse sweep -> slot adjoints -> d(loss)/d(theta).  Three small exchanges per step
+            allreduce_sum_(mom, group)   # `mom` holds this rank's first moments (pass 0, launched by the caller)
+            W, Sx, Sy, _ = mom.tolist()
+            ctx.lit = W > 0.0
+            W = max(W, 1e-12)
+            centroid = target is None
+            cx, cy = (Sx / W, Sy / W) if centroid else (float(target[0]), float(target[1]))
+            mom2 = torch.zeros(6, dtype=torch.float64, device=dev)
+            _spot_moments(x, y, w, mask, 2, cx, cy, W, mom2)
+            allreduce_sum_(mom2, group)
+            dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
+            if ctx.lit:   # the same decision on every rank (W is the global sum): the exchange below pairs up
+                dtheta, _ = _adjoint_sweep(rays_in, prog, table, spot=(sensor_slot, cx, cy, W, mom2[4:6] if centroid else None))
+                allreduce_sum_(dtheta, group)
+            ctx.dtheta = dtheta
+            return mom2[3].clone().reshape(()).to(torch.float32)
         # everything the tangent launches need that does not depend on the centroid goes to the device now, while it
         # is still busy with the trace and the first moments: after the synchronisation below only launches remain
         dp = _tangent_program(prog, table, dev) if n else None

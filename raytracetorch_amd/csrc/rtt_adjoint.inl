@@ -1,0 +1,595 @@
+// rtt_adjoint.inl — reverse-mode backward of the sequential trace (included by rtt_kernels.hip inside its
+// anonymous namespace).
+//
+// What torch autograd does to scene/sequential.py:12-36 of the reference when element parameters or the input rays
+// carry requires_grad (reached through optim/goals.py:144-187 and tests/test_optimize_singlet.py:66-116): every lane
+// re-traces its ray(s) once, keeping the direction in front of every surface it hits and the path length to it (four
+// floats per surface in a lane-private LDS column; the position in front of a surface is the position behind it minus
+// path length times direction), then walks the surfaces back and propagates the adjoint of the ray state through the
+// visit's formulas in reverse.  On the way each visit yields the adjoints of the record
+// slots it read (translations, curvatures, index ratios, ... — the 32 differentiable slots of a record); the slots a
+// caller asked for are summed per lane in LDS, per block in float64, and a second small kernel adds the block sums.
+// The host contracts these slot adjoints with d(slot)/d(parameter), so the kernel's cost does not depend on the number
+// of trainable scalars, and the adjoint that arrives at the start of the ray is the gradient with respect to the input
+// ray itself.
+//
+// Masks, the choice between roots, `entering`, total internal reflection and the Monte-Carlo branch of RefractFresnel
+// are piecewise constant and carry no derivative, as under autograd (torch.where routes by the mask, relu' and abs'
+// follow the sign).  The path length is differentiated implicitly from "t solves A t^2 + B t + C = 0" with the
+// reference's coefficient formulas, like the tangent kernels do.
+
+constexpr int kAdjState = 4;  // floats kept per surface and ray: d (3), t
+
+// Which record slots of which surface get an accumulator: bit j of mask[s] = slot j (Rs 0-8, ts 9-11, Rj 12-20,
+// tj 21-23, geom 24-27, phys 28-31); the accumulators of a surface are consecutive, in slot order, from base[s].
+struct AccMap {
+  uint32_t mask[RTT_MAX_SURFACES];
+  uint16_t base[RTT_MAX_SURFACES];
+};
+
+struct AdjointIO {
+  const float* adj_pos;   // [3][ld_adj] adjoint of the output positions, or null
+  const float* adj_dir;   // [3][ld_adj] adjoint of the output directions, or null
+  int64_t ld_adj;
+  const float* adj_sens;  // [slots][3][sens_ld] adjoint of the recorded hit_local, or null
+  int64_t sens_ld;
+  // spot mode (spot_slot >= 0): the adjoint of hit_local on that sensor slot is formed here from the primal hit,
+  //   g = (x - cx, y - cy) (w/W) / sqrt(((x-cx)^2 + (y-cy)^2) w/W)  -  (w/W) (Gx, Gy)
+  // for hits with intensity w > 0; (Gx, Gy) = sum of the first term over all rays (of all ranks) when the centroid is
+  // the reference point, read from device memory, or absent (null) for a fixed target  (optim/goals.py:170-183)
+  int spot_slot;
+  float cx, cy, inv_w;
+  const double* spot_g;
+  float* ray_adj;  // [6][ld_ray] adjoint of the input rays (pos x, y, z, dir x, y, z), or null
+  int64_t ld_ray;
+  double* partials;  // [gridDim.x][n_acc] block sums of the slot adjoints
+  int n_acc;
+};
+
+DI float hsum(float v) { return v; }
+DI float hsum(f2 v) { return v.x + v.y; }
+
+template <class T>
+struct SlotSink {
+  float* acc;     // this lane's column of the accumulators: accumulator a lives at acc[a * kBlock]
+  uint32_t mask;  // wanted slots of the surface (wave-uniform)
+  int base;
+  typename LaneOf<T>::M on;  // components whose contribution counts: hit and part of the bundle
+  bool all_on;               // `on` holds for the whole wavefront: no select needed
+  DI bool wants(int slot) const { return (mask >> slot) & 1u; }
+  DI bool wants_any(uint32_t slots) const { return (mask & slots) != 0u; }
+  DI void add(int slot, T v) const {
+    if (!wants(slot)) return;  // scalar branch
+    const int a = base + __builtin_popcount(mask & ((1u << slot) - 1u));
+    const float x = all_on ? hsum(v) : hsum(sel(on, v, splat<T>(0.0f)));
+    // the column belongs to this lane alone: a plain read-modify-write (an LDS atomic add measured slower)
+    acc[a * kBlock] += x;
+  }
+};
+
+constexpr uint32_t kSlotsRs = 0x1ffu, kSlotsRj = 0x1ffu << 12;
+
+// dR[3i + j] += a_i b_j for the rotation whose slots start at `first`
+template <class T>
+DI void sink_outer(const SlotSink<T>& sk, int first, V3<T> a, V3<T> b) {
+  sk.add(first + 0, a.x * b.x); sk.add(first + 1, a.x * b.y); sk.add(first + 2, a.x * b.z);
+  sk.add(first + 3, a.y * b.x); sk.add(first + 4, a.y * b.y); sk.add(first + 5, a.y * b.z);
+  sk.add(first + 6, a.z * b.x); sk.add(first + 7, a.z * b.y); sk.add(first + 8, a.z * b.z);
+}
+
+// Adjoint of SurfaceFunction.forward: given g = adjoint of new_dir, returns the adjoints of the incoming direction
+// (db) and of the normal (nb), adds to the adjoint of hit_local (hlb) and hands the slot adjoints to the sink.
+template <class C, class T>
+DI void physics_adjoint(const RecF& S, V3<T> hl, V3<T> d, V3<T> n, V3<T> g, V3<T>& db, V3<T>& nb, V3<T>& hlb,
+                        uint64_t ridx, const SlotSink<T>& sk) {
+  const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
+  db = {zero, zero, zero};
+  nb = {zero, zero, zero};
+  switch (C::pk(S.r)) {
+    case RTT_PHYS_BLOCK:  // new_dir = 0
+      return;
+    case RTT_PHYS_REFLECT: {  // d - 2 (d.n) n
+      const T dot = dot3(d, n), gn = dot3(g, n);
+      db = g - scale(2.0f * gn, n);
+      nb = scale(splat<T>(-2.0f), scale(gn, d) + scale(dot, g));
+      return;
+    }
+    case RTT_PHYS_SNELL:
+    case RTT_PHYS_FRESNEL: {
+      const T dot = dot3(d, n);
+      const auto ent = lt(dot, zero);
+      const T c1 = abs_(dot);
+      const T mu = sel(ent, splat<T>(S.phys(2)), splat<T>(S.phys(3)));
+      const T term = 1.0f - mu * mu * (1.0f - c1 * c1);
+      const T c2 = sqrt_(max_(term, zero));
+      auto mirror = lt(term, zero);  // Snell: total internal reflection
+      if (C::pk(S.r) == RTT_PHYS_FRESNEL) {  // the branch the forward took: u < R, same expressions as apply_physics
+        const T n1 = sel(ent, splat<T>(S.phys(0)), splat<T>(S.phys(1)));
+        const T n2 = sel(ent, splat<T>(S.phys(1)), splat<T>(S.phys(0)));
+        const T sin2 = mu * mu * (1.0f - c1 * c1);
+        const auto tir = gt(sin2, one);
+        const T ct = sqrt_(max_(1.0f - sin2, zero));
+        const T n1ci = n1 * c1, n2ct = n2 * ct, n1ct = n1 * ct, n2ci = n2 * c1;
+        const T rs = quot(n1ci - n2ct, n1ci + n2ct + 1e-8f);
+        const T rp = quot(n1ct - n2ci, n1ct + n2ci + 1e-8f);
+        const T R = sel(tir, one, 0.5f * (rs * rs + rp * rp));
+        const uint64_t key = ((uint64_t)S.r.seed[1] << 32 | S.r.seed[0]) + ((uint64_t)S.r.element_id << 8) + (uint64_t)S.r.surface_id;
+        mirror = lt(fresnel_uniform(key, ridx, 0u, (T*)nullptr), R);
+      }
+      // refraction: mu d + sg (mu c1 - c2) n, sg = +1 entering, -1 leaving
+      const T sg = sel(ent, one, splat<T>(-1.0f));
+      const T gn = dot3(g, n), gd = dot3(g, d);
+      const T gb = sg * gn;  // adjoint of (mu c1 - c2)
+      const auto lit = gt(term, zero);
+      const T termb = sel(lit, -gb * 0.5f * rcp_(c2), zero);  // c2 = sqrt(relu(term))
+      T mub = gd + c1 * gb - termb * (2.0f * mu * (1.0f - c1 * c1));
+      const T c1b = mu * gb + termb * (2.0f * mu * mu * c1);
+      const T dotb = sel(lt(dot, zero), -c1b, sel(gt(dot, zero), c1b, zero));  // c1 = |dot|
+      const T coef = sg * (mu * c1 - c2);
+      db = scale(mu, g) + scale(dotb, n);
+      nb = scale(coef, g) + scale(dotb, d);
+      if (__any(any_(mirror))) {  // d - 2 (d.n) n
+        db = sel3(mirror, g - scale(2.0f * gn, n), db);
+        nb = sel3(mirror, scale(splat<T>(-2.0f), scale(gn, d) + scale(dot, g)), nb);
+        mub = sel(mirror, zero, mub);
+      }
+      sk.add(30, sel(ent, mub, zero));
+      sk.add(31, sel(ent, zero, mub));
+      return;
+    }
+    case RTT_PHYS_LINEAR: {  // phys/std.py:72-88
+      const V3<T> dl = rowmat<2>(d, S, false);
+      const T rz = div_ieee(one, dl.z);
+      const T qx = dl.x * rz, qy = dl.y * rz;
+      const T nx = splat<T>(S.phys(0)) * hl.x + splat<T>(S.phys(2)) * qx;
+      const T ny = splat<T>(S.phys(1)) * hl.y + splat<T>(S.phys(3)) * qy;
+      const T rl = div_ieee(one, sqrt_ieee(nx * nx + ny * ny + 1.0f));
+      const V3<T> o = {nx * rl, ny * rl, rl};
+      const V3<T> ob = rowmat<2>(g, S, false);  // new_dir = o @ Rp^T
+      const T oo = dot3(o, ob);
+      const T nxb = (ob.x - o.x * oo) * rl, nyb = (ob.y - o.y * oo) * rl;
+      sk.add(28, nxb * hl.x);
+      sk.add(29, nyb * hl.y);
+      sk.add(30, nxb * qx);
+      sk.add(31, nyb * qy);
+      hlb.x = hlb.x + nxb * S.phys(0);
+      hlb.y = hlb.y + nyb * S.phys(1);
+      const T qxb = nxb * S.phys(2), qyb = nyb * S.phys(3);
+      const V3<T> dlb = {qxb * rz, qyb * rz, -(qxb * qx + qyb * qy) * rz};
+      db = rowmat_t<2>(dlb, S, false);
+      if ((S.r.flags & RTT_F_PHYS_ROT_SURF) && sk.wants_any(kSlotsRj)) {
+        sink_outer(sk, 12, d, dlb);  // dl = d @ Rj
+        sink_outer(sk, 12, g, o);    // new_dir_i = sum_j o_j Rj[3i + j]
+      }
+      return;
+    }
+    case RTT_PHYS_APERTURE: {  // dir * m
+      const T m = sel(surface_in_bounds<C>(S, hl), one, zero);
+      db = scale(m, g);
+      return;
+    }
+    default:  // transmit
+      db = g;
+      return;
+  }
+}
+
+// Adjoint of _getNormal in the surface frame: nlb = adjoint of the local normal nl at the local hit point h.
+template <class C, class T>
+DI void normal_adjoint(const RecF& S, V3<T> h, V3<T> nl, V3<T> nlb, V3<T>& hb, const SlotSink<T>& sk) {
+  const T zero = splat<T>(0.0f);
+  switch (C::sk(S.r)) {
+    case RTT_SURF_PLANE:
+      return;
+    case RTT_SURF_SPHERE: {  // h / R
+      const T rR = rcp_(splat<T>(S.geom(0)));
+      hb = hb + scale(rR, nlb);
+      sk.add(24, -dot3(nlb, nl) * rR);
+      return;
+    }
+    case RTT_SURF_CYLINDER: {  // (x, y, 0) / R
+      const T rR = rcp_(splat<T>(S.geom(0)));
+      hb.x = hb.x + nlb.x * rR;
+      hb.y = hb.y + nlb.y * rR;
+      sk.add(24, -(nlb.x * nl.x + nlb.y * nl.y) * rR);
+      return;
+    }
+    case RTT_SURF_QUADRIC:
+    case RTT_SURF_QUADRIC_ZY: {  // -v / (|v| + 1e-8), v = (2c x, 2c y, 2c(1+k) z - 2)
+      const bool full = C::sk(S.r) == RTT_SURF_QUADRIC;
+      const float two_c = 2.0f * S.geom(0), two_c1k = 2.0f * S.geom(2);
+      const T vx = full ? two_c * h.x : zero, vy = two_c * h.y, vz = two_c1k * h.z - 2.0f;
+      const T L = sqrt_(vx * vx + vy * vy + vz * vz);
+      const T rlen = rcp_(L + 1e-8f), rL = rcp_(L);
+      const T nn = dot3(nlb, nl);
+      // vb = -nlb / len + (nlb . nl) nl / L
+      const V3<T> vb = scale(nn * rL, nl) - scale(rlen, nlb);
+      if (full) hb.x = hb.x + two_c * vb.x;
+      hb.y = hb.y + two_c * vb.y;
+      hb.z = hb.z + two_c1k * vb.z;
+      sk.add(24, 2.0f * ((full ? h.x * vb.x : zero) + h.y * vb.y));
+      sk.add(26, 2.0f * (h.z * vb.z));
+      return;
+    }
+    default: {  // cone: v / (|v| + 1e-8) with v = (-k2 x, -k2 y, z), +z where |v| <= 1e-8
+      const float k2 = S.geom(1);
+      const T vx = -k2 * h.x, vy = -k2 * h.y, vz = h.z;
+      const T L = sqrt_(vx * vx + vy * vy + vz * vz);
+      const auto ok = gt(L, splat<T>(1e-8f));
+      const T rl = rcp_(L + 1e-8f), rL = rcp_(L);
+      const T nn = dot3(nlb, nl);
+      V3<T> vb = scale(rl, nlb) - scale(nn * rL, nl);
+      vb = sel3(ok, vb, V3<T>{zero, zero, zero});
+      hb.x = hb.x - k2 * vb.x;
+      hb.y = hb.y - k2 * vb.y;
+      hb.z = hb.z + vb.z;
+      sk.add(25, -(h.x * vb.x + h.y * vb.y));
+      return;
+    }
+  }
+}
+
+// Adjoint of the path length: t solves A t^2 + B t + C = 0 (coefficients of the surface kind in o = pl, d = dl), so
+//   dt = -(go . d(o) + gd . d(d) + g0 d(geom[i0]) + g1 d(geom[i1])) / den
+// with the same coefficient vectors as the tangent kernels; tb is the adjoint of t.
+template <class C, class T>
+DI void root_adjoint(const RecF& S, V3<T> o, V3<T> d, T t, V3<T> h, T tb, V3<T>& ob, V3<T>& db, const SlotSink<T>& sk) {
+  const T zero = splat<T>(0.0f);
+  const T eps = splat<T>(kEps);
+  V3<T> go, gd;
+  T g0 = zero, g1 = zero, den;
+  int i0 = 0, i1 = -1;
+  switch (C::sk(S.r)) {
+    case RTT_SURF_PLANE: {  // t = -o.z / safe(d.z); the guarded denominator is a constant
+      const auto guard = lt(abs_(d.z), eps);
+      den = sel(guard, splat<T>(1e-8f), d.z);
+      go = {zero, zero, splat<T>(1.0f)};
+      gd = {zero, zero, sel(guard, zero, t)};
+      i0 = -1;
+      break;
+    }
+    case RTT_SURF_SPHERE:  // t^2 + 2 (o.d) t + o.o - R^2
+      go = scale(splat<T>(2.0f), h);
+      gd = scale(2.0f * t, o);
+      g0 = splat<T>(-1.0f);
+      i0 = 1;
+      den = 2.0f * t + 2.0f * dot3(o, d);
+      break;
+    case RTT_SURF_CYLINDER:
+      go = {2.0f * h.x, 2.0f * h.y, zero};
+      gd = {t * go.x, t * go.y, zero};
+      g0 = splat<T>(-1.0f);
+      i0 = 1;
+      den = 2.0f * (d.x * d.x + d.y * d.y) * t + 2.0f * (o.x * d.x + o.y * d.y);
+      break;
+    case RTT_SURF_QUADRIC:
+    case RTT_SURF_QUADRIC_ZY: {
+      const float c = S.geom(0), c1k = S.geom(2);
+      const float kx = C::sk(S.r) == RTT_SURF_QUADRIC ? 1.0f : 0.0f;
+      const T A = c * (kx * d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
+      const T B = 2.0f * c * (kx * o.x * d.x + o.y * d.y) + 2.0f * c1k * o.z * d.z - 2.0f * d.z;
+      go = {2.0f * c * kx * h.x, 2.0f * c * h.y, 2.0f * c1k * h.z - 2.0f};
+      i0 = 0;
+      i1 = 2;
+      gd = scale(t, go);
+      g0 = kx * h.x * h.x + h.y * h.y;
+      g1 = h.z * h.z;
+      den = 2.0f * A * t + B;
+      const auto lin = lt(abs_(A), eps);  // the reference's linear root -C / B_safe: the A term is dropped
+      if (__any(any_(lin))) {
+        const V3<T> gd_lin = {t * (2.0f * c * kx) * o.x, t * (2.0f * c) * o.y, t * (2.0f * c1k * o.z - 2.0f)};
+        gd = sel3(lin, gd_lin, gd);
+        g0 = sel(lin, 2.0f * t * (kx * o.x * d.x + o.y * d.y) + (kx * o.x * o.x + o.y * o.y), g0);
+        g1 = sel(lin, 2.0f * t * o.z * d.z + o.z * o.z, g1);
+        den = sel(lin, sel(lt(abs_(B), eps), eps, B), den);
+      }
+      break;
+    }
+    default: {  // cone: A = dz^2 - k2 (dx^2 + dy^2), B = 2 (oz dz - k2 (ox dx + oy dy)), C = oz^2 - k2 (ox^2 + oy^2)
+      const float k2 = S.geom(1);
+      const T A = d.z * d.z - k2 * (d.x * d.x + d.y * d.y);
+      const T B = 2.0f * (o.z * d.z - k2 * (o.x * d.x + o.y * d.y));
+      go = {-2.0f * k2 * h.x, -2.0f * k2 * h.y, 2.0f * h.z};
+      i0 = 1;
+      const auto lin = lt(abs_(A), eps);
+      const V3<T> gd_lin = {-2.0f * k2 * t * o.x, -2.0f * k2 * t * o.y, 2.0f * t * o.z};
+      gd = sel3(lin, gd_lin, scale(t, go));
+      g0 = sel(lin, -(2.0f * t * (o.x * d.x + o.y * d.y) + (o.x * o.x + o.y * o.y)), -(h.x * h.x + h.y * h.y));
+      den = sel(lin, sel(lt(abs_(B), eps), eps, B), 2.0f * A * t + B);
+      break;
+    }
+  }
+  const T s = -tb * rcp_(den);
+  ob = ob + scale(s, go);
+  db = db + scale(s, gd);
+  if (i0 >= 0) sk.add(24 + i0, s * g0);
+  if (i1 >= 0) sk.add(24 + i1, s * g1);
+}
+
+// Adjoint of one surface visit for the components where `hit`: (p, d, t) are the state in front of the surface and the
+// path length the forward sweep kept; pb / db come in as the adjoints of the state behind the surface and leave as
+// the adjoints of the state in front of it.  `ext(hl)` supplies the adjoint that reaches hit_local from outside the
+// trace (a sensor's record), evaluated at the recomputed local hit point.
+template <class C, class T, class M, class Ext>
+DI void visit_adjoint(const RecF& S, V3<T> p, V3<T> d, T t, M hit, V3<T>& pb, V3<T>& db, uint64_t ridx,
+                      const SlotSink<T>& sk, Ext&& ext) {
+  const T zero = splat<T>(0.0f);
+  const bool shp = C::has_shape(S.r), ids = C::rs_id(S.r), idj = C::rj_id(S.r);
+  // ---- the forward quantities again (to_frames, surface_forward) ----
+  V3<T> q = p, pe = p, de = d, den = d;
+  T rinv = splat<T>(1.0f);
+  auto norm_live = mask_all<M>(true);
+  if (shp) {
+    q = p - V3<T>{splat<T>(S.ts(0)), splat<T>(S.ts(1)), splat<T>(S.ts(2))};
+    pe = rowmat<0>(q, S, ids);
+    de = rowmat<0>(d, S, ids);
+    const T n2 = dot3(de, de);
+    if (kStrict) {
+      rinv = div_ieee(splat<T>(1.0f), max_(sqrt_ieee(n2), splat<T>(1e-12f)));
+    } else {
+      rinv = rsq_(max_(n2, splat<T>(1e-24f)));
+    }
+    norm_live = gt(n2, splat<T>(1e-24f));  // below the clamp the divisor is a constant
+    den = scale(rinv, de);
+  }
+  const V3<T> u = pe - V3<T>{splat<T>(S.tj(0)), splat<T>(S.tj(1)), splat<T>(S.tj(2))};
+  const V3<T> pl = rowmat<1>(u, S, idj);
+  const V3<T> dl = rowmat<1>(den, S, idj);
+  const V3<T> hl = pl + scale(t, dl);
+  const V3<T> nl = surface_normal<C>(S, hl);
+  const V3<T> n1 = rowmat_t<1>(nl, S, idj);
+  const V3<T> n = shp ? rowmat_t<0>(n1, S, ids) : n1;
+  // ---- physics: new_dir(hl, d, n) ----
+  V3<T> hlb = ext(hl);
+  V3<T> dpb, nb;
+  physics_adjoint<C>(S, hl, d, n, db, dpb, nb, hlb, ridx, sk);
+  // ---- normal: n = (nl @ Rj^T) @ Rs^T ----
+  const V3<T> n1b = shp ? rowmat<0>(nb, S, ids) : nb;
+  const V3<T> nlb = rowmat<1>(n1b, S, idj);
+  normal_adjoint<C>(S, hl, nl, nlb, hlb, sk);
+  // ---- hit_local = pl + t dl, hit_global = p + t d ----
+  V3<T> plb = hlb, dlb = scale(t, hlb);
+  const T tb = dot3(hlb, dl) + dot3(pb, d);
+  V3<T> p_in = pb;
+  V3<T> d_in = dpb + scale(t, pb);
+  root_adjoint<C>(S, pl, dl, t, hl, tb, plb, dlb, sk);
+  // ---- frames: pl = (pe - tj) @ Rj, dl = den @ Rj, den = de / |de|, pe = (p - ts) @ Rs, de = d @ Rs ----
+  const V3<T> ub = rowmat_t<1>(plb, S, idj);
+  const V3<T> denb = rowmat_t<1>(dlb, S, idj);
+  sk.add(21, -ub.x);
+  sk.add(22, -ub.y);
+  sk.add(23, -ub.z);
+  V3<T> deb = denb;
+  if (shp) {
+    const T along = dot3(den, denb);
+    deb = denb - scale(along, den);
+    if (!__all(all_(norm_live))) deb = sel3(norm_live, deb, denb);
+    deb = scale(rinv, deb);
+    const V3<T> qb = rowmat_t<0>(ub, S, ids);
+    p_in = p_in + qb;
+    sk.add(9, -qb.x);
+    sk.add(10, -qb.y);
+    sk.add(11, -qb.z);
+    d_in = d_in + rowmat_t<0>(deb, S, ids);
+    if (sk.wants_any(kSlotsRs)) {
+      sink_outer(sk, 0, q, ub);   // pe = q @ Rs
+      sink_outer(sk, 0, d, deb);  // de = d @ Rs
+      sink_outer(sk, 0, nb, n1);  // n_i = sum_j n1_j Rs[3i + j]
+    }
+  } else {
+    p_in = p_in + ub;
+    d_in = d_in + denb;
+  }
+  if (sk.wants_any(kSlotsRj)) {
+    sink_outer(sk, 12, u, plb);
+    sink_outer(sk, 12, den, dlb);
+    sink_outer(sk, 12, n1b, nl);  // n1_i = sum_j nl_j Rj[3i + j]
+  }
+  if (sk.all_on) {  // every component of the wavefront hit: plain moves
+    pb = p_in;
+    db = d_in;
+  } else {
+    pb = sel3(hit, p_in, pb);
+    db = sel3(hit, d_in, db);
+  }
+  (void)zero;
+}
+
+template <class T> struct HitBits { uint64_t b[LaneOf<T>::N]; };
+
+template <class T, class M>
+DI void set_bits(HitBits<T>& hb, int s, M hit) {
+#pragma unroll
+  for (int k = 0; k < LaneOf<T>::N; ++k) hb.b[k] |= (uint64_t)(mcomp(hit, k) ? 1u : 0u) << s;
+}
+template <class T>
+DI typename LaneOf<T>::M get_bits(const HitBits<T>& hb, int s) {
+  auto m = mask_all<typename LaneOf<T>::M>(false);
+#pragma unroll
+  for (int k = 0; k < LaneOf<T>::N; ++k) m = set_mask(m, k, ((hb.b[k] >> s) & 1ull) != 0);
+  return m;
+}
+
+template <class I> DI float ldp_(const float* p, I i, bool, int, float*) { return p[i]; }
+template <class I> DI f2 ldp_(const float* p, I i, bool vec, int nv, f2*) {
+  if (vec && nv == 2) return *reinterpret_cast<const f2*>(p + i);
+  return f2{p[i], p[i + (nv - 1)]};
+}
+
+// dynamic LDS: float acc[n_acc][kBlock], then T state[n_surf][kAdjState][kBlock]
+// Three wavefronts per SIMD is what the LDS of a four-surface program allows with two rays per lane (four with one);
+// the register allocation is held to that.
+template <class T>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+                                                              Ops ops, AccMap am, AdjointIO a, int vec) {
+  extern __shared__ float lds_dyn[];
+  constexpr int N = LaneOf<T>::N;
+  using M = typename LaneOf<T>::M;
+  const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
+  float* acc = lds_dyn + threadIdx.x;
+  T* state = reinterpret_cast<T*>(lds_dyn + (int64_t)a.n_acc * kBlock) + threadIdx.x;
+  for (int k = 0; k < a.n_acc; ++k) acc[k * kBlock] = 0.0f;
+  float Gx = 0.0f, Gy = 0.0f;
+  if (a.spot_slot >= 0 && a.spot_g) {
+    Gx = (float)a.spot_g[0];
+    Gy = (float)a.spot_g[1];
+  }
+  const int64_t tile = (int64_t)kBlock * N;
+  const int64_t stride = (int64_t)gridDim.x * tile;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < io.n; base += stride) {
+    const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in, nullptr, nullptr, nullptr, 0, io.n - base};
+    const uint32_t idx = threadIdx.x * N;
+    const int64_t left = tio.n - (int64_t)idx;
+    const int nv = left >= N ? N : (left >= 1 ? 1 : 0);
+    // lanes past the end trace a copy of the tile's first ray and contribute nothing
+    Ray<T> r = load_ray<T>(tio, nv ? idx : 0u, vec != 0 && nv == N, nv ? nv : 1);
+    M live = mask_all<M>(false);
+#pragma unroll
+    for (int k = 0; k < N; ++k) live = set_mask(live, k, k < nv);
+    const uint64_t ridx = (uint64_t)(base + idx);
+    HitBits<T> bits;
+#pragma unroll
+    for (int k = 0; k < N; ++k) bits.b[k] = 0ull;
+    T w_spot = splat<T>(0.0f);
+    // ---- forward sweep: keep the state in front of every surface that is hit ----
+    for (int s = 0; s < n_surf; ++s) {
+      const RecF S{prog[s]};
+      Frames<T> f;
+      T t_raw;
+      M hit;
+#define RTT_CALL(CFG)                                                                                  \
+  {                                                                                                    \
+    hit = test_surface<CFG>(S, r.p, r.d, f, t_raw);                                                    \
+    if (__any(any_(hit))) {                                                                            \
+      T* st = state + (int64_t)s * kAdjState * kBlock;                                                 \
+      st[0] = r.d.x; st[kBlock] = r.d.y; st[2 * kBlock] = r.d.z; st[3 * kBlock] = t_raw;               \
+      const Forward<T> fw = surface_forward<CFG>(S, r.p, r.d, f, t_raw);                               \
+      V3<T> nd;                                                                                        \
+      T im;                                                                                            \
+      apply_physics<CFG>(S, fw.hit_l, r.d, fw.n_g, nd, im, ridx, 0u);                                  \
+      if ((S.r.flags & RTT_F_SENSOR) && S.r.sensor_slot == a.spot_slot) w_spot = sel(hit, r.I, w_spot); \
+      if (__all(all_(hit))) {                                                                          \
+        r.p = fw.hit_g;                                                                                \
+        r.d = nd;                                                                                      \
+        r.I = r.I * im;                                                                                \
+      } else {                                                                                         \
+        r.p = sel3(hit, fw.hit_g, r.p);                                                                \
+        r.d = sel3(hit, nd, r.d);                                                                      \
+        r.I = sel(hit, r.I * im, r.I);                                                                 \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+#undef RTT_CALL
+      set_bits(bits, s, hit);
+    }
+    // ---- adjoint of the final state ----
+    T* tag = nullptr;
+    const T zero = splat<T>(0.0f);
+    V3<T> pb = {zero, zero, zero}, db = {zero, zero, zero};
+    const uint32_t at = nv ? idx : 0u;
+    const bool vload = vec != 0 && nv == N && (a.ld_adj % 2 == 0);
+    if (a.adj_pos) {
+      const float* ap = a.adj_pos + base;
+      pb = {ldp_(ap, at, vload, nv ? nv : 1, tag), ldp_(ap + a.ld_adj, at, vload, nv ? nv : 1, tag),
+            ldp_(ap + 2 * a.ld_adj, at, vload, nv ? nv : 1, tag)};
+    }
+    if (a.adj_dir) {
+      const float* ad = a.adj_dir + base;
+      db = {ldp_(ad, at, vload, nv ? nv : 1, tag), ldp_(ad + a.ld_adj, at, vload, nv ? nv : 1, tag),
+            ldp_(ad + 2 * a.ld_adj, at, vload, nv ? nv : 1, tag)};
+    }
+    // ---- reverse sweep: r.p walks back from the final position ----
+    for (int s = n_surf - 1; s >= 0; --s) {
+      const M hit = get_bits(bits, s);
+      if (!__any(any_(hit))) continue;
+      const RecF S{prog[s]};
+      const T* st = state + (int64_t)s * kAdjState * kBlock;
+      const V3<T> d = {st[0], st[kBlock], st[2 * kBlock]};
+      const T t = st[3 * kBlock];
+      const M on = and_(hit, live);
+      const bool all_on = __all(all_(on));
+      // position in front of the surface: the hit point minus path length times direction (the forward's
+      // hit_global = p + t d); components that did not hit this surface did not move
+      if (all_on) {
+        r.p = r.p - scale(t, d);
+      } else {
+        r.p = sel3(hit, r.p - scale(t, d), r.p);
+      }
+      const V3<T> p = r.p;
+      const SlotSink<T> sk = {acc, am.mask[s], (int)am.base[s], on, all_on};
+      const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
+      const int slot = S.r.sensor_slot;
+      auto ext = [&](V3<T> hl) -> V3<T> {
+        V3<T> g = {zero, zero, zero};
+        if (!sensor) return g;
+        if (a.spot_slot >= 0) {
+          if (slot != a.spot_slot) return g;
+          const T wn = w_spot * a.inv_w;
+          const T dx = hl.x - a.cx, dy = hl.y - a.cy;
+          const T uu = sqrt_ieee((dx * dx + dy * dy) * wn);
+          const T inv = sel(gt(uu, zero), div_ieee(wn, uu), zero);
+          const auto on = gt(w_spot, zero);
+          g.x = sel(on, dx * inv - wn * Gx, zero);
+          g.y = sel(on, dy * inv - wn * Gy, zero);
+          return g;
+        }
+        if (a.adj_sens) {
+          const float* as = a.adj_sens + (int64_t)slot * 3 * a.sens_ld + base;
+          const bool vs = vec != 0 && nv == N && (a.sens_ld % 2 == 0);
+          g = {ldp_(as, at, vs, nv ? nv : 1, tag), ldp_(as + a.sens_ld, at, vs, nv ? nv : 1, tag),
+               ldp_(as + 2 * a.sens_ld, at, vs, nv ? nv : 1, tag)};
+          // entries of rays that did not hit the sensor are not part of the record
+          g = sel3(hit, g, V3<T>{zero, zero, zero});
+        }
+        return g;
+      };
+#define RTT_CALL(CFG) visit_adjoint<CFG>(S, p, d, t, hit, pb, db, ridx, sk, ext)
+      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+#undef RTT_CALL
+    }
+    if (a.ray_adj && nv) {
+      float* ra = a.ray_adj + base;
+      const bool vst = vec != 0 && nv == N && (a.ld_ray % 2 == 0);
+      const T comps[6] = {pb.x, pb.y, pb.z, db.x, db.y, db.z};
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        float* plane = ra + (int64_t)c * a.ld_ray;
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (k < nv) plane[idx + k] = comp(comps[c], k);
+        (void)vst;
+      }
+    }
+  }
+  // ---- block sums of the slot adjoints, float64 ----
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = wv; k < a.n_acc; k += kBlock / 64) {
+    const float* col = lds_dyn + (int64_t)k * kBlock;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < kBlock / 64; ++j) v += (double)col[lane + 64 * j];
+    v = wave_sum(v);
+    if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;
+  }
+}
+
+// out[k] = sum over blocks of partials[b][k]; one block per accumulator, fixed order: the result does not depend on
+// the order in which the blocks of the first kernel finished
+__global__ void __launch_bounds__(kBlock) k_sum_partials(const double* __restrict__ partials, int n_blocks, int n_acc,
+                                                         double* __restrict__ out) {
+  __shared__ double part[kBlock / 64];
+  const int k = blockIdx.x;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < n_blocks; b += kBlock) v += partials[(int64_t)b * n_acc + k];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) s += part[w];
+    out[k] = s;
+  }
+}

@@ -1309,6 +1309,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq_tangent(RayIO io, const Rt
   }
 }
 
+#include "rtt_adjoint.inl"
+
 // ------------------------------------------------------------------------------------------------
 // Scene.ray_cast / Scene.step (scene/base.py:144-235)
 // ------------------------------------------------------------------------------------------------
@@ -1842,6 +1844,8 @@ __global__ void __launch_bounds__(kBlock) k_apply_physics(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // One entry of the spot-size sums.  pass 0: W, sum w x, sum w y; pass 1: sum sqrt(((x-cx)^2 + (y-cy)^2) w / W) with
 // the per-ray term in float32 like the reference's tensors.  All sums in float64.
+// pass 2: the same sum and, beside it, sum g with g = (x - cx, y - cy) (w/W) / sqrt(((x-cx)^2 + (y-cy)^2) w/W), the
+// two sums the centroid term of the loss gradient needs (optim/goals.py:176-182 under autograd).
 DI void spot_term(int pass, float xi, float yi, float wi, bool masked_in, double cx, double cy, float wsum,
                   double& a0, double& a1, double& a2) {
   if (!(masked_in && wi > 0.0f)) return;
@@ -1852,7 +1856,14 @@ DI void spot_term(int pass, float xi, float yi, float wi, bool masked_in, double
     a2 += wd * yd;
   } else {
     const float dx = (float)(xd - cx), dy = (float)(yd - cy);
-    a0 += (double)sqrtf((dx * dx + dy * dy) * (wi / wsum));
+    const float wn = wi / wsum;
+    const float u = sqrtf((dx * dx + dy * dy) * wn);
+    a0 += (double)u;
+    if (pass == 2) {
+      const float inv = u > 0.0f ? wn / u : 0.0f;
+      a1 += (double)(dx * inv);
+      a2 += (double)(dy * inv);
+    }
   }
 }
 
@@ -1907,6 +1918,10 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
       atomicAdd(&out[2], s2);
     } else {
       atomicAdd(&out[3], s0);
+      if (pass == 2) {
+        atomicAdd(&out[4], s1);
+        atomicAdd(&out[5], s2);
+      }
     }
   }
 }
@@ -2517,6 +2532,115 @@ int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const 
   return launch_tangent<true>(io, prog_dev, prog_host, n_surf, tio, n_theta, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+namespace {
+
+constexpr int kAdjMaxBlocks = 2048;          // grid cap of the adjoint kernel = rows of its block-sum workspace
+constexpr int kAdjMaxAcc = 128;              // accumulators per launch
+constexpr int kLdsBytes = 160 * 1024;        // LDS of a gfx950 compute unit
+int g_adjoint_lane = 0;                      // 0: choose by LDS need, 1: one ray per lane, 2: two rays per lane
+
+int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane) {
+  return (int64_t)kBlock * 4 * ((int64_t)n_acc + (int64_t)n_surf * kAdjState * rays_per_lane);
+}
+
+template <class T>
+int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
+                   int vec, int64_t lds, int blocks, hipStream_t st) {
+  static bool raised = false;  // dynamic LDS above 64 KB has to be granted once per kernel
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsBytes) != hipSuccess)
+      return RTT_E_LAUNCH;
+    raised = true;
+  }
+  hipLaunchKernelGGL((k_trace_seq_adjoint<T>), dim3(blocks), dim3(kBlock), (size_t)lds, st, io, prog_dev, n_surf, ops, am, a, vec);
+  return launch_status();
+}
+
+// Shared body of the two adjoint entry points: `partials` is the block-sum scratch ([kAdjMaxBlocks][n_acc] doubles).
+int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                      const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
+                      const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
+                      int spot_slot, double cx, double cy, double wsum, const double* spot_g, float* ray_adj, int64_t ld_ray,
+                      double* slot_adj, double* partials, int64_t partial_rows, hipStream_t st) {
+  if (!pos_in || !dir_in || !inten_in || !prog_dev || !prog_host) return RTT_E_NULL;
+  if (n < 0 || ld_in < n) return RTT_E_SIZE;
+  if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
+  if (adj_sens && sens_ld < n) return RTT_E_SIZE;
+  if (ray_adj && ld_ray < n) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(adj_pos) || misaligned(adj_dir) ||
+      misaligned(adj_sens) || misaligned(ray_adj) || (reinterpret_cast<uintptr_t>(slot_adj) & 7u) ||
+      (reinterpret_cast<uintptr_t>(partials) & 7u) || (reinterpret_cast<uintptr_t>(spot_g) & 7u))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (spot_slot >= RTT_MAX_SURFACES || (spot_slot >= 0 && !(wsum > 0.0))) return RTT_E_SIZE;
+  AccMap am = {};
+  int n_acc = 0;
+  for (int s = 0; s < n_surf; ++s) {
+    am.mask[s] = slot_mask ? slot_mask[s] : 0u;
+    am.base[s] = (uint16_t)n_acc;
+    n_acc += __builtin_popcount(am.mask[s]);
+  }
+  if (n_acc > kAdjMaxAcc) return RTT_E_SIZE;
+  if (n_acc > 0 && (!slot_adj || !partials)) return RTT_E_NULL;
+  int lanes = g_adjoint_lane;
+  if (lanes == 0) lanes = adjoint_lds_bytes(n_surf, n_acc, 2) <= kLdsBytes / 2 ? 2 : 1;
+  const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes);
+  if (lds > kLdsBytes) return RTT_E_SIZE;
+  if (n == 0) {
+    if (n_acc > 0 && hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) != hipSuccess) return RTT_E_LAUNCH;
+    return RTT_OK;
+  }
+  const int64_t tile = (int64_t)kBlock * lanes;
+  int64_t blocks = (n + tile - 1) / tile;
+  if (blocks > kAdjMaxBlocks) blocks = kAdjMaxBlocks;
+  if (n_acc > 0 && blocks > partial_rows) return RTT_E_SIZE;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
+  AdjointIO a = {adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, spot_slot, (float)cx, (float)cy,
+                 spot_slot >= 0 ? (float)(1.0 / wsum) : 0.0f, spot_g, ray_adj, ld_ray, partials, n_acc};
+  const Ops ops = make_ops(prog_host, n_surf);
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (ld_in % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) && aligned8(adj_pos) &&
+                  aligned8(adj_dir) && aligned8(adj_sens);
+  rc = lanes == 2 ? launch_adjoint<f2>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                  : launch_adjoint<float>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+  if (rc != RTT_OK || n_acc == 0) return rc;
+  hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, n_acc, slot_adj);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtt_trace_seq_adjoint_max_slots(int n_surf) {
+  if (n_surf < 1 || n_surf > RTT_MAX_SURFACES) return 0;
+  const int64_t room = (kLdsBytes - adjoint_lds_bytes(n_surf, 0, 1)) / (kBlock * 4);
+  return room < 0 ? 0 : (room > kAdjMaxAcc ? kAdjMaxAcc : (int)room);
+}
+
+int64_t rtt_trace_seq_adjoint_workspace_bytes(int n_slots) {
+  return n_slots < 0 ? 0 : (int64_t)sizeof(double) * kAdjMaxBlocks * n_slots;
+}
+
+int rtt_trace_seq_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
+                              const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
+                              int spot_slot, double cx, double cy, double wsum, const double* spot_g, float* ray_adj,
+                              int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes, void* stream) {
+  int n_acc = 0;
+  if (slot_mask && n_surf >= 1 && n_surf <= RTT_MAX_SURFACES)
+    for (int s = 0; s < n_surf; ++s) n_acc += __builtin_popcount(slot_mask[s]);
+  const int64_t rows = n_acc > 0 ? workspace_bytes / ((int64_t)sizeof(double) * n_acc) : 0;
+  return trace_seq_adjoint(pos_in, dir_in, inten_in, ld_in, n, prog_dev, prog_host, n_surf, slot_mask, adj_pos, adj_dir, ld_adj,
+                           adj_sens, sens_ld, spot_slot, cx, cy, wsum, spot_g, ray_adj, ld_ray, slot_adj, (double*)workspace, rows,
+                           (hipStream_t)stream);
+}
+
 int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, const RttSurface* prog_dev,
                      const RttSurface* prog_host, int n_surf, int32_t* winner, float* tmin, void* stream) {
   if (!pos || !dir || !prog_dev) return RTT_E_NULL;
@@ -2616,7 +2740,7 @@ static int moments_grid(int64_t n) {
 int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n, int pass,
                          double cx, double cy, double wsum, double* out, void* stream) {
   if (!x || !y || !w || !out) return RTT_E_NULL;
-  if (n < 0 || (pass != 0 && pass != 1)) return RTT_E_SIZE;
+  if (n < 0 || pass < 0 || pass > 2) return RTT_E_SIZE;
   if (misaligned(x) || misaligned(y) || misaligned(w) || (reinterpret_cast<uintptr_t>(out) & 7u)) return RTT_E_ALIGN;
   if (n == 0) return RTT_OK;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -2818,6 +2942,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 5 && value >= 1 && value <= (1 << 20)) {
     g_reduction_blocks = value;
+    return RTT_OK;
+  }
+  if (key == 6 && value >= 0 && value <= 2) {
+    g_adjoint_lane = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;

@@ -1,0 +1,206 @@
+"""GPU: the reverse-mode backward of the sequential trace (rtt_trace_seq_adjoint_f32) against the forward-mode
+kernels (rtt_trace_seq_tangent_f32 / _ray_adjoint_f32), which differentiate the same formulas independently.  The
+goldens from the reference's autograd are checked in tests/test_gpu_autograd.py through whichever mode is the default;
+here the two modes are held against each other, the entry point is called directly through the C ABI, and the
+LDS-budget edges (slot masks split over several launches, programs too long for the kernel) are exercised."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from util import golden
+
+import raytracetorch_amd.autograd as AG
+import raytracetorch_amd.program as P
+from raytracetorch_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _grads(ns, build, objective, mode, monkeypatch, calls=None):
+    monkeypatch.setenv("RTT_BACKWARD", mode)
+    torch.manual_seed(0)
+    els, rays = build()
+    params = {k: p for k, p in torch.nn.ModuleList(els).named_parameters() if p.requires_grad}
+    if rays._pos.is_leaf:
+        rays._pos.requires_grad_(True)
+        rays._dir.requires_grad_(True)
+    if calls is not None:
+        lib, real = N.lib(), N.lib().rtt_trace_seq_adjoint_f32
+
+        def counted(*a):
+            calls.append(1)
+            return real(*a)
+        monkeypatch.setattr(lib, "rtt_trace_seq_adjoint_f32", counted, raising=False)
+    obj = objective(els, rays)
+    obj.backward()
+    out = {k: p.grad.detach().double().cpu().reshape(-1) for k, p in params.items() if p.grad is not None}
+    out["rays.pos"] = rays._pos.grad.detach().double().cpu().reshape(-1)
+    out["rays.dir"] = rays._dir.grad.detach().double().cpu().reshape(-1)
+    return float(obj.detach()), out
+
+
+def _projection(ns, seed):
+    def objective(els, rays):
+        g = torch.Generator().manual_seed(seed)
+        n = len(rays)
+        wp, wd, ws = (torch.randn(n, 3, generator=g).to(DEV) for _ in range(3))
+        src_pos, src_dir = rays._pos, rays._dir
+        r = ns.SequentialScene(els).simulate(ns.Rays.from_planes(src_pos, src_dir, rays.intensity, rays.id, rays.wavelength))
+        obj = (r.pos * wp).sum() + (r.dir * wd).sum()
+        for el in els:
+            if hasattr(el, "getHitsTensors") and el.hitLocs:
+                locs, w, _ = el.getHitsTensors()
+                obj = obj + (locs * ws[: locs.shape[0]] * w[:, None]).sum()
+        return obj
+    return objective
+
+
+def _compare(a, b, tol=3e-4):
+    assert set(a) == set(b)
+    for k in a:
+        scale = max(1.0, float(b[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= tol * scale, (k, a[k], b[k])
+
+
+CASES = {
+    "spot_system": lambda ns: list(scenes.spot_system(ns, grads=True)),
+    "tilted": lambda ns: list(scenes.tilt_system(ns, [0.03, -0.02, 0.1])),
+    "identity_rotation": lambda ns: list(scenes.tilt_system(ns, [0.0, 0.0, 0.0])),
+    "system5": lambda ns: scenes.system5(ns),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_reverse_and_forward_mode_agree(ns, name, monkeypatch):
+    def build():
+        els = CASES[name](ns)
+        scenes.make_all_trainable(els)
+        rays = scenes.disk_bundle(ns, radius=4.5, z=-30.0, rot=[0.01, -0.02, 0.0]).sample(5001).to(DEV)
+        return els, rays
+    calls = []
+    obj_a, ga = _grads(ns, build, _projection(ns, 3), "adjoint", monkeypatch, calls)
+    assert calls, "the reverse-mode entry point was not used"
+    obj_t, gt = _grads(ns, build, _projection(ns, 3), "tangent", monkeypatch)
+    assert obj_a == obj_t
+    assert len(ga) > 4
+    _compare(ga, gt)
+
+
+@pytest.mark.parametrize("gen", ["random_system", "random_system_extra"])
+@pytest.mark.parametrize("seed", range(12))
+def test_random_systems_in_both_modes(ns, gen, seed, monkeypatch):
+    """Every element kind of the random generators (doublets, cylindrical lenses, boxes, cones, ideal elements,
+    mirrors, stops) with every floating-point parameter trainable, and gradients with respect to the rays."""
+    def build():
+        els = getattr(scenes, gen)(ns, np.random.default_rng(seed))
+        scenes.make_all_trainable(els)
+        rays = scenes.disk_bundle(ns, radius=5.0, z=-15.0, rot=[0.03 * math.sin(seed), 0.02, 0.0]).sample(1501).to(DEV)
+        return els, rays
+    obj_a, ga = _grads(ns, build, _projection(ns, seed), "adjoint", monkeypatch)
+    obj_t, gt = _grads(ns, build, _projection(ns, seed), "tangent", monkeypatch)
+    if not np.isfinite(obj_t):
+        pytest.skip("objective not finite for this system (NaN roots of unbounded surfaces)")
+    assert obj_a == obj_t
+    # both are float32 evaluations of the same derivative; ill-conditioned systems (paraboloids, long free paths)
+    # amplify the rounding of either, so the bar is relative to the largest gradient of the system
+    big = max(float(v.abs().max()) for v in gt.values())
+    for k in gt:
+        assert float((ga[k] - gt[k]).abs().max()) <= 2e-3 * max(1.0, big), (k, ga[k], gt[k])
+
+
+def _many_singlets(ns, count):
+    els = [scenes.singlet(ns, c1=0.02, c2=-0.02, d=12.0, t=1.0, c1_grad=True, c2_grad=True, t_grad=True, ior_glass_grad=True,
+                          transform=ns.RayTransform(translation=[0.0, 0.0, 3.0 * k])) for k in range(count)]
+    return els + [ns.Sensor(ns.Disk(20.0, transform=ns.RayTransform(translation=[0.0, 0.0, 3.0 * count + 2.0])))]
+
+
+@pytest.mark.parametrize("count,launches", [(10, "several"), (13, None)])
+def test_slot_budget_edges(ns, count, launches, monkeypatch):
+    """31 surfaces leave room for 36 slot accumulators per launch, fewer than the wanted slots of ten trainable
+    singlets, which therefore take several launches; 40 surfaces leave none and the forward-mode kernels take over."""
+    def build():
+        return _many_singlets(ns, count), scenes.disk_bundle(ns, radius=3.0, z=-10.0).sample(3001).to(DEV)
+    n_surf = 3 * count + 1
+    budget = N.lib().rtt_trace_seq_adjoint_max_slots(n_surf)
+    assert budget == max(0, 160 - 4 * n_surf)
+    calls = []
+    obj_a, ga = _grads(ns, build, _projection(ns, 1), "adjoint", monkeypatch, calls)
+    obj_t, gt = _grads(ns, build, _projection(ns, 1), "tangent", monkeypatch)
+    assert obj_a == obj_t
+    if launches is None:
+        assert budget == 0 and not calls
+    else:
+        assert len(calls) >= 2, (len(calls), budget)
+    _compare(ga, gt)
+
+
+def test_entry_point_directly(ns):
+    """Through the C ABI: the adjoint of one record slot, summed over the rays, equals the forward-mode contraction
+    with the unit tangent of that slot; the input-ray adjoint equals the per-ray forward-mode one; two calls give the
+    same bits (the block sums are added in a fixed order)."""
+    lib = N.lib()
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    prog = P.compile_elements([lens, sensor])
+    n = 40001
+    rays = scenes.disk_bundle(ns, radius=4.0, z=-30.0, rot=[0.01, 0.02, 0.0]).sample(n).to(DEV)
+    dp = N.DeviceProgram.upload(prog, DEV)
+    g = torch.Generator().manual_seed(5)
+    adj_pos, adj_dir = (torch.randn(3, n, generator=g).to(DEV) for _ in range(2))
+    adj_sens = torch.randn(1, 3, n, generator=g).to(DEV)
+    pairs = [(0, 23), (0, 24), (0, 26), (0, 30), (1, 23), (1, 24), (1, 31), (3, 21), (3, 23)]
+    masks = np.zeros(4, dtype=np.uint32)
+    for s, j in pairs:
+        masks[s] |= np.uint32(1 << j)
+    order = sorted(pairs)
+    outs = []
+    for _ in range(2):
+        slot_adj = torch.empty(len(pairs), dtype=torch.float64, device=DEV)
+        ray_adj = torch.empty((6, n), device=DEV)
+        ws = torch.empty(int(lib.rtt_trace_seq_adjoint_workspace_bytes(len(pairs))), dtype=torch.uint8, device=DEV)
+        code = lib.rtt_trace_seq_adjoint_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev),
+                                             dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+                                             -1, 0.0, 0.0, 1.0, 0, N.ptr(ray_adj), n, N.ptr(slot_adj), N.ptr(ws), ws.numel(),
+                                             N.stream_handle(DEV))
+        N.check(code, "rtt_trace_seq_adjoint_f32")
+        outs.append((slot_adj.cpu(), ray_adj.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    table = np.zeros((4, 32, len(order)), dtype=np.float32)
+    for k, (s, j) in enumerate(order):
+        table[s, j, k] = 1.0
+    want = AG._tangent_contract(rays, prog, table, adj_pos, adj_dir, adj_sens).cpu()
+    scale = float(want.abs().max())
+    assert float((outs[0][0] - want).abs().max()) <= 2e-4 * scale, (outs[0][0], want)
+    want_rays = AG._ray_adjoint(rays, prog, adj_pos, adj_dir, adj_sens).cpu()
+    assert float((outs[0][1] - want_rays).abs().max()) <= 2e-4 * float(want_rays.abs().max())
+    # one ray per lane and two rays per lane run the same arithmetic per ray
+    assert lib.rtt_tune(6, 1) == 0
+    try:
+        slot_adj = torch.empty(len(pairs), dtype=torch.float64, device=DEV)
+        code = lib.rtt_trace_seq_adjoint_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev),
+                                             dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+                                             -1, 0.0, 0.0, 1.0, 0, 0, 0, N.ptr(slot_adj), N.ptr(ws), ws.numel(), N.stream_handle(DEV))
+        N.check(code, "rtt_trace_seq_adjoint_f32")
+        assert float((slot_adj.cpu() - outs[0][0]).abs().max()) <= 1e-5 * scale
+    finally:
+        lib.rtt_tune(6, 0)
+
+
+def test_forward_mode_still_reproduces_the_reference(ns, monkeypatch):
+    """The spot-size gradients of the reference's autograd through the forward-mode kernels (the default path is
+    checked against the same golden in tests/test_gpu_autograd.py)."""
+    monkeypatch.setenv("RTT_BACKWARD", "tangent")
+    g = golden("spot_f32")
+    torch.manual_seed(0)
+    lens, sensor = scenes.spot_system(ns, grads=True)
+    loss = ns.SpotSizeLoss(sensor, [scenes.disk_bundle(ns)], N_rays=65536)(ns.SequentialScene([lens, sensor]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    s0, s1 = lens.shape.surfaces[0], lens.shape.surfaces[1]
+    got = dict(c1=s0.c.grad, c2=s1.c.grad, ior_glass=lens.ior_glass.grad)
+    for k, v in got.items():
+        assert abs(float(v) - float(g["g_" + k])) <= 2e-4 * abs(float(g["g_" + k])), k
