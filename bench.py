@@ -304,6 +304,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
     else:
         lens, sensor = scenes.spot_system(ns, grads=True)
         scene = ns.SequentialScene([lens, sensor])
+        scene.to(dev)   # trainable parameters resident on the GPU (what project.load_scene leaves): the step never waits for the host
         if dist is not None:
             scene.grad_group = dist.group.WORLD
         surfaces = 4

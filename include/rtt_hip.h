@@ -178,9 +178,12 @@ int rtt_trace_seq_spot_grad_f32(const float* pos_in, const float* dir_in, const 
  *   slot_adj   device array of one float64 per set bit, ordered by surface and, within a surface, by slot; overwritten;
  *   adj_pos, adj_dir, adj_sens   upstream adjoints as for rtt_trace_seq_tangent_f32 (each nullable);
  *   spot_slot >= 0 instead forms the upstream adjoint of the spot-size loss in the kernel, on the hits of that sensor
- *     slot with intensity w > 0:  g = (x-cx, y-cy)(w/W)/sqrt(((x-cx)^2+(y-cy)^2) w/W) - (w/W)(Gx, Gy), W = wsum, and
- *     (Gx, Gy) read from the two float64 at spot_g (device memory: the sums of the first term over all rays, e.g.
- *     out[4..5] of rtt_spot_moments_f32 pass 2, reduced over ranks) or taken as zero when spot_g is NULL (fixed target);
+ *     slot with intensity w > 0:  g = (x-cx, y-cy)(w/W)/sqrt(((x-cx)^2+(y-cy)^2) w/W) - (w/W)(Gx, Gy).
+ *     With spot_mom (device memory: the six float64 sums of rtt_spot_moments_f32, [W, sum w x, sum w y, sum sqrt, Gx, Gy],
+ *     reduced over ranks) W = max(spot_mom[0], 1e-12) and, when spot_centroid != 0, the centre is the centroid
+ *     spot_mom[1..2] / W and (Gx, Gy) = spot_mom[4..5]; with spot_centroid == 0 the centre is (cx, cy) and (Gx, Gy) = 0.
+ *     Without spot_mom (NULL): centre (cx, cy), W = wsum, (Gx, Gy) = 0 — a fixed target with sums known on the host.
+ *     Reading the sums from device memory lets a caller chain moments and backward without a host round trip;
  *   ray_adj    (nullable) [6][ld_ray]: adjoint of the input rays, as rtt_trace_seq_ray_adjoint_f32 returns it;
  *   workspace  device scratch for the per-block sums, rtt_trace_seq_adjoint_workspace_bytes(number of set bits) bytes.
  * Limits: rtt_trace_seq_adjoint_max_slots(n_surf) set bits per call (the per-surface ray states and the per-lane sums
@@ -191,8 +194,9 @@ int64_t rtt_trace_seq_adjoint_workspace_bytes(int n_slots);
 int rtt_trace_seq_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
                               const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
                               const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
-                              int spot_slot, double cx, double cy, double wsum, const double* spot_g, float* ray_adj,
-                              int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes, void* stream);
+                              int spot_slot, int spot_centroid, double cx, double cy, double wsum, const double* spot_mom,
+                              float* ray_adj, int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes,
+                              void* stream);
 
 /* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
  * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
@@ -278,7 +282,10 @@ int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float*
  * pass 0: out[0..2] += sum w, sum w x, sum w y over entries with mask != 0 and w > 0.
  * pass 1: out[3] += sum sqrt(((x-cx)^2 + (y-cy)^2) * (w / wsum)) over the same entries.
  * pass 2: pass 1 and out[4..5] += sum g, g = (x-cx, y-cy)(w/wsum)/sqrt(((x-cx)^2+(y-cy)^2) w/wsum): what the centroid
- *         term of the loss gradient needs (rtt_trace_seq_adjoint_f32, spot_g); `out` then holds 6 doubles.
+ *         term of the loss gradient needs (rtt_trace_seq_adjoint_f32, spot_mom); `out` then holds 6 doubles.
+ * pass 3: pass 2 with wsum = max(out[0], 1e-12) and the centre (out[1], out[2]) / wsum read from `out` itself, i.e. from
+ *         the (rank-reduced) result of pass 0: the chain pass 0 -> centroid -> pass 3 needs no host round trip.
+ * pass 4: pass 2 with wsum = max(out[0], 1e-12) read from `out` and the centre (cx, cy) as given (fixed target).
  * `out` is 4 doubles in device memory that the caller zeroes before pass 0. */
 int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n,
                          int pass, double cx, double cy, double wsum, double* out, void* stream);

@@ -177,18 +177,40 @@ def _slot_pairs(table):
     return np.argwhere(np.any(table != 0.0, axis=2))
 
 
-def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=None, want_ray_adj=False, spot=None):
+def _adjoint_plan(table, budget, dev, derived=None):
+    """Launches of the reverse sweep for a tangent table: [(slot masks [n_surf] uint32, number of slot sums, device
+    matrix [slot sums, n_theta] float64 that turns the slot adjoints into d/d(theta))], at most `budget` slot sums
+    per launch.  `derived` (a dict that lives as long as the table) keeps the plan, so that a table which is reused
+    costs no host-to-device transfer: such a transfer from pageable memory waits for the stream."""
+    key = ("adjoint plan", str(dev), budget)
+    if derived is not None and key in derived:
+        return derived[key]
+    pairs = _slot_pairs(table)
+    plan = []
+    for k in range(0, max(len(pairs), 1), max(budget, 1)):
+        chunk = pairs[k:k + budget]
+        masks = np.zeros(table.shape[0], dtype=np.uint32)
+        for sfc, slt in chunk:
+            masks[sfc] |= np.uint32(1) << np.uint32(slt)
+        rows = torch.from_numpy(table[chunk[:, 0], chunk[:, 1], :].astype(np.float64)).to(dev) if len(chunk) else None
+        plan.append((masks, len(chunk), rows))
+    if derived is not None:
+        derived[key] = plan
+    return plan
+
+
+def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=None, want_ray_adj=False, spot=None,
+                   derived=None):
     """Reverse-mode backward of the sequential trace: (d objective / d theta [n_theta] float64 on the device,
     [6, N] adjoint of the input rays or None).  The objective is given by the upstream adjoints of the output planes
-    and of the sensor records, or, with `spot` = (sensor slot, cx, cy, W, device tensor of (Gx, Gy) or None), by the
-    spot-size loss whose adjoint the kernel forms itself.  Returns None when the program is too long for the
-    kernel's LDS budget (the caller then uses the forward-mode kernels)."""
+    and of the sensor records, or, with `spot` = (sensor slot, centroid?, target x, target y, device tensor of the six
+    moment sums), by the spot-size loss whose adjoint the kernel forms itself from those sums.  Returns None when the
+    program is too long for the kernel's LDS budget (the caller then uses the forward-mode kernels)."""
     n, dev = len(rays_in), rays_in.device
     n_surf, n_theta = table.shape[0], table.shape[2]
     lib = N.lib()
     budget = lib.rtt_trace_seq_adjoint_max_slots(n_surf)
-    pairs = _slot_pairs(table)
-    if budget == 0 and (len(pairs) or want_ray_adj):
+    if budget == 0:
         return None
     dtheta = torch.zeros(n_theta, dtype=torch.float64, device=dev)
     ray_adj = torch.zeros((6, n), dtype=torch.float32, device=dev) if want_ray_adj else None
@@ -197,13 +219,9 @@ def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=No
     dp = N.DeviceProgram.upload(prog, dev)
     fix = lambda a: None if a is None else a.contiguous().to(torch.float32)
     adj_pos, adj_dir, adj_sens = fix(adj_pos), fix(adj_dir), fix(adj_sens)
-    slot, cx, cy, wsum, g_dev = (-1, 0.0, 0.0, 1.0, None) if spot is None else spot
-    chunks = [pairs[k:k + budget] for k in range(0, len(pairs), budget)] if len(pairs) else [pairs]
-    for c, chunk in enumerate(chunks):
-        masks = np.zeros(n_surf, dtype=np.uint32)
-        for sfc, slt in chunk:
-            masks[sfc] |= np.uint32(1) << np.uint32(slt)
-        n_acc = len(chunk)
+    slot, centroid, cx, cy, mom_dev = (-1, False, 0.0, 0.0, None) if spot is None else spot
+    plan = _adjoint_plan(table, budget, dev, derived)
+    for c, (masks, n_acc, rows) in enumerate(plan):
         slot_adj = torch.empty(max(n_acc, 1), dtype=torch.float64, device=dev)
         ws_bytes = int(lib.rtt_trace_seq_adjoint_workspace_bytes(n_acc))
         ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
@@ -213,12 +231,12 @@ def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=No
                 N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
                 N.ptr(dp.dev), dp.host_ptr, dp.n, masks.ctypes.data,
                 N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
-                int(slot), float(cx), float(cy), float(wsum), N.ptr(g_dev),
+                int(slot), int(bool(centroid)), float(cx), float(cy), 1.0, N.ptr(mom_dev),
                 N.ptr(ray_adj) if first else 0, n, N.ptr(slot_adj), N.ptr(ws), ws_bytes, N.stream_handle(dev))
         N.check(code, "rtt_trace_seq_adjoint_f32")
         if n_acc:
-            rows = torch.from_numpy(table[chunk[:, 0], chunk[:, 1], :].astype(np.float64)).to(dev, non_blocking=True)
-            dtheta += slot_adj[:n_acc] @ rows
+            contribution = slot_adj[:n_acc] @ rows
+            dtheta = contribution if len(plan) == 1 else dtheta + contribution
     return dtheta, ray_adj
 
 
@@ -498,10 +516,11 @@ def _chunks(table, widest=6):
         k0 += used
 
 
-def _assemble_grads(dtheta, thetas, param_meta, param_ids):
+def _assemble_grads(dtheta, thetas, param_meta, param_ids, derived=None):
     """Per-parameter gradient tensors from the flat vector d(loss)/d(theta_k).  Parameters that live on the device
     of `dtheta` get theirs by one scatter on that device, with no synchronisation (the host may run ahead into the
-    next step); otherwise one device-to-host transfer and the scatter on the host."""
+    next step; `derived`, a dict that lives as long as the parameter list, keeps the scatter index on the device);
+    otherwise one device-to-host transfer and the scatter on the host."""
     sizes = [int(np.prod(shape, dtype=np.int64)) for shape, _, _ in param_meta]
     starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     where = {pid: k for k, pid in enumerate(param_ids)}
@@ -509,7 +528,13 @@ def _assemble_grads(dtheta, thetas, param_meta, param_ids):
     if param_meta and all(dev == dtheta.device for _, _, dev in param_meta):
         flat = torch.zeros(int(starts[-1]), dtype=torch.float64, device=dtheta.device)
         if dst:
-            flat.index_copy_(0, torch.tensor(dst, dtype=torch.int64).to(dtheta.device, non_blocking=True), dtheta)
+            key = ("scatter index", str(dtheta.device), tuple(dst))
+            index = None if derived is None else derived.get(key)
+            if index is None:
+                index = torch.tensor(dst, dtype=torch.int64).to(dtheta.device)
+                if derived is not None:
+                    derived[key] = index
+            flat.index_copy_(0, index, dtheta)
     else:
         flat = torch.zeros(int(starts[-1]), dtype=torch.float64)
         if dst:
@@ -530,30 +555,31 @@ class FusedSpotLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_in, prog, table, thetas, group, target, sensor_slot, sens, mom, *params):
+        table, derived = table   # the slot Jacobians and the dict of device objects derived from them
         hit, w, mask = sens  # dense record of the sensor slot from the forward trace
         x, y = hit[0], hit[1]
         n, dev = len(rays_in), rays_in.device
-        ctx.thetas = thetas
+        ctx.thetas, ctx.derived = thetas, derived
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
         if backward_mode() == "adjoint" and N.lib().rtt_trace_seq_adjoint_max_slots(int(table.shape[0])) > 0:
-            # reverse mode: first moments -> centroid; second pass -> loss and the centroid term (Gx, Gy), which stay
-            # on the device; one reverse sweep -> slot adjoints -> d(loss)/d(theta).  Three small exchanges per step
-            allreduce_sum_(mom, group)   # `mom` holds this rank's first moments (pass 0, launched by the caller)
-            W, Sx, Sy, _ = mom.tolist()
-            ctx.lit = W > 0.0
-            W = max(W, 1e-12)
+            # Reverse mode, without a host round trip: the six moment sums stay on the device.  `mom` holds this rank's
+            # first moments (pass 0, launched by the caller); the second pass reads weight and centroid from it and adds
+            # the loss sum and the centroid term (Gx, Gy); the reverse sweep reads all of them and yields the slot
+            # adjoints, which one small matrix product turns into d(loss)/d(theta).  Three small exchanges per step.
+            allreduce_sum_(mom[0:3], group)
             centroid = target is None
-            cx, cy = (Sx / W, Sy / W) if centroid else (float(target[0]), float(target[1]))
-            mom2 = torch.zeros(6, dtype=torch.float64, device=dev)
-            _spot_moments(x, y, w, mask, 2, cx, cy, W, mom2)
-            allreduce_sum_(mom2, group)
-            dtheta = torch.zeros(table.shape[2], dtype=torch.float64, device=dev)
-            if ctx.lit:   # the same decision on every rank (W is the global sum): the exchange below pairs up
-                dtheta, _ = _adjoint_sweep(rays_in, prog, table, spot=(sensor_slot, cx, cy, W, mom2[4:6] if centroid else None))
-                allreduce_sum_(dtheta, group)
+            tx, ty = (0.0, 0.0) if centroid else (float(target[0]), float(target[1]))
+            _spot_moments(x, y, w, mask, 3 if centroid else 4, tx, ty, 1.0, mom)
+            allreduce_sum_(mom[3:6], group)
+            # nothing lit on any rank: every sum is zero and no ray carries a seed, so loss and gradients come out as
+            # zeros by themselves; `lit` only tells the caller not to count this bundle (optim/goals.py:165-167)
+            dtheta, _ = _adjoint_sweep(rays_in, prog, table, spot=(sensor_slot, centroid, tx, ty, mom), derived=derived)
+            allreduce_sum_(dtheta, group)
             ctx.dtheta = dtheta
-            return mom2[3].clone().reshape(()).to(torch.float32)
+            lit = (mom[0] > 0).to(torch.float32)
+            ctx.mark_non_differentiable(lit)
+            return mom[3].to(torch.float32), lit
         # everything the tangent launches need that does not depend on the centroid goes to the device now, while it
         # is still busy with the trace and the first moments: after the synchronisation below only launches remain
         dp = _tangent_program(prog, table, dev) if n else None
@@ -563,11 +589,12 @@ class FusedSpotLossFn(torch.autograd.Function):
             staged.append((k0, used, width, torch.from_numpy(padded).to(dev) if n else None,
                            torch.zeros(3 * width + 3, dtype=torch.float64, device=dev)))   # the kernel fills 3 width + 2
         allreduce_sum_(mom, group)   # `mom` holds this rank's first moments (pass 0, launched by the caller)
-        W, Sx, Sy, _ = mom.tolist()
+        W, Sx, Sy = mom.tolist()[:3]
         ctx.lit = W > 0.0
         W = max(W, 1e-12)
         centroid = target is None
         cx, cy = (Sx / W, Sy / W) if centroid else (float(target[0]), float(target[1]))
+        mom = mom[:4].clone()
         mom[3] = 0.0
         _spot_moments(x, y, w, mask, 1, cx, cy, W, mom)
         loss = None   # this rank's sum; it travels with the first gradient chunk, one exchange for both
@@ -594,11 +621,13 @@ class FusedSpotLossFn(torch.autograd.Function):
         ctx.dtheta, ctx.thetas = dtheta, thetas
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
-        return loss.reshape(()).to(torch.float32)
+        lit = torch.tensor(1.0 if ctx.lit else 0.0, device=dev)
+        ctx.mark_non_differentiable(lit)
+        return loss.reshape(()).to(torch.float32), lit
 
     @staticmethod
-    def backward(ctx, g):
-        grads = _assemble_grads(ctx.dtheta * g.to(torch.float64), ctx.thetas, ctx.param_meta, ctx.param_ids)
+    def backward(ctx, g, _glit=None):
+        grads = _assemble_grads(ctx.dtheta * g.to(torch.float64), ctx.thetas, ctx.param_meta, ctx.param_ids, ctx.derived)
         return (None,) * 9 + tuple(grads)
 
 
@@ -620,20 +649,34 @@ def _cached_scalars(elements, params=None):
     return hit[2]
 
 
-def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None, params=None):
+def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None, params=None, table_cache=None):
     """Differentiable spot-size loss of a bundle already traced (forward only, no graph) through `prog`;
-    `sens` = (hit [3,N], w [N], mask [N]) of the sensor slot, `rays` the *input* bundle of that trace."""
+    `sens` = (hit [3,N], w [N], mask [N]) of the sensor slot, `rays` the *input* bundle of that trace.
+    Returns (loss, lit): `lit` is a 0/1 tensor on the device, 0 when nothing lit reached the sensor on any rank (the
+    reference skips such a bundle, optim/goals.py:165-167; the loss is then 0 with zero gradients).  Neither is read
+    on the host here, so the caller's step stays asynchronous."""
     hit, w, mask = sens
     # first moments right behind the trace; the host work below overlaps both kernels
-    mom = torch.zeros(4, device=w.device, dtype=torch.float64)
+    mom = torch.zeros(6, device=w.device, dtype=torch.float64)
     _spot_moments(hit[0], hit[1], w, mask, 0, 0.0, 0.0, 1.0, mom)
     thetas = _cached_scalars(elements, params)
-    table = tangent_table(elements, thetas)
+    # `table_cache` = (dict owned by the scene, key of the scene's parameter state): the slot Jacobians are derived
+    # again only when a parameter changed (for device-resident parameters deriving them costs a device-to-host
+    # transfer, i.e. a synchronisation)
+    table = derived = None
+    if table_cache is not None:
+        holder, state = table_cache
+        key = (state, tuple((id(p), i) for p, i in thetas))
+        kept = holder.get("_tangent_table")
+        if kept is not None and kept[0] == key:
+            table, derived = kept[1], kept[2]
+    if table is None:
+        table, derived = tangent_table(elements, thetas), {}
+        if table_cache is not None:
+            holder["_tangent_table"] = (key, table, derived)
     params, seen = [], set()
     for p, _ in thetas:
         if id(p) not in seen:
             seen.add(id(p))
             params.append(p)
-    loss = FusedSpotLossFn.apply(rays, prog, table, thetas, group, target, sensor_slot, sens, mom, *params)
-    # no lit hit on any rank: the reference skips such a bundle (optim/goals.py:165-167)
-    return loss if loss.grad_fn is None or loss.grad_fn.lit else None
+    return FusedSpotLossFn.apply(rays, prog, (table, derived), thetas, group, target, sensor_slot, sens, mom, *params)

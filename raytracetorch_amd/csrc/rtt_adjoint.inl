@@ -3,10 +3,11 @@
 //
 // What torch autograd does to scene/sequential.py:12-36 of the reference when element parameters or the input rays
 // carry requires_grad (reached through optim/goals.py:144-187 and tests/test_optimize_singlet.py:66-116): every lane
-// re-traces its ray(s) once, keeping the direction in front of every surface it hits and the path length to it (four
-// floats per surface in a lane-private LDS column; the position in front of a surface is the position behind it minus
-// path length times direction), then walks the surfaces back and propagates the adjoint of the ray state through the
-// visit's formulas in reverse.  On the way each visit yields the adjoints of the record
+// re-traces its ray(s) once, keeping the state in front of every surface it hits (position, direction, path length:
+// seven floats per surface in a lane-private LDS column), then walks the surfaces back and propagates the adjoint of
+// the ray state through the visit's formulas in reverse.  (Keeping only direction and path length and walking the
+// position back, p - t d, was measured: 5 % faster, but behind a long free path the subtraction loses the low bits of
+// the position and the gradients of ill-conditioned systems moved by 1e-3.)  On the way each visit yields the adjoints of the record
 // slots it read (translations, curvatures, index ratios, ... — the 32 differentiable slots of a record); the slots a
 // caller asked for are summed per lane in LDS, per block in float64, and a second small kernel adds the block sums.
 // The host contracts these slot adjoints with d(slot)/d(parameter), so the kernel's cost does not depend on the number
@@ -18,7 +19,7 @@
 // follow the sign).  The path length is differentiated implicitly from "t solves A t^2 + B t + C = 0" with the
 // reference's coefficient formulas, like the tangent kernels do.
 
-constexpr int kAdjState = 4;  // floats kept per surface and ray: d (3), t
+constexpr int kAdjState = 7;  // floats kept per surface and ray: p (3), d (3), t
 
 // Which record slots of which surface get an accumulator: bit j of mask[s] = slot j (Rs 0-8, ts 9-11, Rj 12-20,
 // tj 21-23, geom 24-27, phys 28-31); the accumulators of a surface are consecutive, in slot order, from base[s].
@@ -35,11 +36,13 @@ struct AdjointIO {
   int64_t sens_ld;
   // spot mode (spot_slot >= 0): the adjoint of hit_local on that sensor slot is formed here from the primal hit,
   //   g = (x - cx, y - cy) (w/W) / sqrt(((x-cx)^2 + (y-cy)^2) w/W)  -  (w/W) (Gx, Gy)
-  // for hits with intensity w > 0; (Gx, Gy) = sum of the first term over all rays (of all ranks) when the centroid is
-  // the reference point, read from device memory, or absent (null) for a fixed target  (optim/goals.py:170-183)
-  int spot_slot;
+  // for hits with intensity w > 0 (optim/goals.py:170-183).  spot_mom (device, nullable) = the six sums of the moment
+  // passes [W, sum w x, sum w y, sum sqrt, Gx, Gy]: W comes from it; with spot_centroid the centre is the centroid
+  // (sum w x, sum w y) / W and (Gx, Gy) the sums of the first term over all rays, otherwise the centre is (cx, cy)
+  // and (Gx, Gy) = 0.  Without spot_mom: centre (cx, cy), 1 / W = inv_w, (Gx, Gy) = 0.
+  int spot_slot, spot_centroid;
   float cx, cy, inv_w;
-  const double* spot_g;
+  const double* spot_mom;
   float* ray_adj;  // [6][ld_ray] adjoint of the input rays (pos x, y, z, dir x, y, z), or null
   int64_t ld_ray;
   double* partials;  // [gridDim.x][n_acc] block sums of the slot adjoints
@@ -417,10 +420,9 @@ template <class I> DI f2 ldp_(const float* p, I i, bool vec, int nv, f2*) {
 }
 
 // dynamic LDS: float acc[n_acc][kBlock], then T state[n_surf][kAdjState][kBlock]
-// Three wavefronts per SIMD is what the LDS of a four-surface program allows with two rays per lane (four with one);
-// the register allocation is held to that.
+// Two wavefronts per SIMD is what the LDS of a four-surface program allows with two rays per lane (three with one).
 template <class T>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                               Ops ops, AccMap am, AdjointIO a, int vec) {
   extern __shared__ float lds_dyn[];
   constexpr int N = LaneOf<T>::N;
@@ -429,10 +431,16 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
   float* acc = lds_dyn + threadIdx.x;
   T* state = reinterpret_cast<T*>(lds_dyn + (int64_t)a.n_acc * kBlock) + threadIdx.x;
   for (int k = 0; k < a.n_acc; ++k) acc[k * kBlock] = 0.0f;
-  float Gx = 0.0f, Gy = 0.0f;
-  if (a.spot_slot >= 0 && a.spot_g) {
-    Gx = (float)a.spot_g[0];
-    Gy = (float)a.spot_g[1];
+  float Gx = 0.0f, Gy = 0.0f, cx = a.cx, cy = a.cy, inv_w = a.inv_w;
+  if (a.spot_slot >= 0 && a.spot_mom) {
+    const double W = fmax(a.spot_mom[0], 1e-12);  // the reference clamps the weight sum (optim/goals.py:173)
+    inv_w = (float)(1.0 / W);
+    if (a.spot_centroid) {
+      cx = (float)(a.spot_mom[1] / W);
+      cy = (float)(a.spot_mom[2] / W);
+      Gx = (float)a.spot_mom[4];
+      Gy = (float)a.spot_mom[5];
+    }
   }
   const int64_t tile = (int64_t)kBlock * N;
   const int64_t stride = (int64_t)gridDim.x * tile;
@@ -462,7 +470,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
     hit = test_surface<CFG>(S, r.p, r.d, f, t_raw);                                                    \
     if (__any(any_(hit))) {                                                                            \
       T* st = state + (int64_t)s * kAdjState * kBlock;                                                 \
-      st[0] = r.d.x; st[kBlock] = r.d.y; st[2 * kBlock] = r.d.z; st[3 * kBlock] = t_raw;               \
+      st[0] = r.p.x; st[kBlock] = r.p.y; st[2 * kBlock] = r.p.z;                                       \
+      st[3 * kBlock] = r.d.x; st[4 * kBlock] = r.d.y; st[5 * kBlock] = r.d.z; st[6 * kBlock] = t_raw;  \
       const Forward<T> fw = surface_forward<CFG>(S, r.p, r.d, f, t_raw);                               \
       V3<T> nd;                                                                                        \
       T im;                                                                                            \
@@ -499,24 +508,17 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
       db = {ldp_(ad, at, vload, nv ? nv : 1, tag), ldp_(ad + a.ld_adj, at, vload, nv ? nv : 1, tag),
             ldp_(ad + 2 * a.ld_adj, at, vload, nv ? nv : 1, tag)};
     }
-    // ---- reverse sweep: r.p walks back from the final position ----
+    // ---- reverse sweep ----
     for (int s = n_surf - 1; s >= 0; --s) {
       const M hit = get_bits(bits, s);
       if (!__any(any_(hit))) continue;
       const RecF S{prog[s]};
       const T* st = state + (int64_t)s * kAdjState * kBlock;
-      const V3<T> d = {st[0], st[kBlock], st[2 * kBlock]};
-      const T t = st[3 * kBlock];
+      const V3<T> p = {st[0], st[kBlock], st[2 * kBlock]};
+      const V3<T> d = {st[3 * kBlock], st[4 * kBlock], st[5 * kBlock]};
+      const T t = st[6 * kBlock];
       const M on = and_(hit, live);
       const bool all_on = __all(all_(on));
-      // position in front of the surface: the hit point minus path length times direction (the forward's
-      // hit_global = p + t d); components that did not hit this surface did not move
-      if (all_on) {
-        r.p = r.p - scale(t, d);
-      } else {
-        r.p = sel3(hit, r.p - scale(t, d), r.p);
-      }
-      const V3<T> p = r.p;
       const SlotSink<T> sk = {acc, am.mask[s], (int)am.base[s], on, all_on};
       const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
       const int slot = S.r.sensor_slot;
@@ -525,8 +527,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
         if (!sensor) return g;
         if (a.spot_slot >= 0) {
           if (slot != a.spot_slot) return g;
-          const T wn = w_spot * a.inv_w;
-          const T dx = hl.x - a.cx, dy = hl.y - a.cy;
+          const T wn = w_spot * inv_w;
+          const T dx = hl.x - cx, dy = hl.y - cy;
           const T uu = sqrt_ieee((dx * dx + dy * dy) * wn);
           const T inv = sel(gt(uu, zero), div_ieee(wn, uu), zero);
           const auto on = gt(w_spot, zero);

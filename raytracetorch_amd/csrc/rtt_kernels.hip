@@ -1877,6 +1877,16 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
                                                          double* __restrict__ out) {
   __shared__ double part[3][kBlock / 64];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (pass >= 3) {
+    // passes 3 and 4 are pass 2 with the weight sum taken from out[0] (clamped like the reference's W) and, in pass 3,
+    // the centre from out[1..2] / W: the first moments never leave the device
+    wsum = fmax(out[0], 1e-12);
+    if (pass == 3) {
+      cx = out[1] / wsum;
+      cy = out[2] / wsum;
+    }
+    pass = 2;
+  }
   const float wsum_f = (float)wsum;
   constexpr int W = VEC ? 4 : 1;
   const int64_t stride = (int64_t)gridDim.x * kBlock * W;
@@ -2563,8 +2573,8 @@ int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, cons
 int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
                       const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
                       const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
-                      int spot_slot, double cx, double cy, double wsum, const double* spot_g, float* ray_adj, int64_t ld_ray,
-                      double* slot_adj, double* partials, int64_t partial_rows, hipStream_t st) {
+                      int spot_slot, int spot_centroid, double cx, double cy, double wsum, const double* spot_mom, float* ray_adj,
+                      int64_t ld_ray, double* slot_adj, double* partials, int64_t partial_rows, hipStream_t st) {
   if (!pos_in || !dir_in || !inten_in || !prog_dev || !prog_host) return RTT_E_NULL;
   if (n < 0 || ld_in < n) return RTT_E_SIZE;
   if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
@@ -2572,12 +2582,12 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   if (ray_adj && ld_ray < n) return RTT_E_SIZE;
   if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(adj_pos) || misaligned(adj_dir) ||
       misaligned(adj_sens) || misaligned(ray_adj) || (reinterpret_cast<uintptr_t>(slot_adj) & 7u) ||
-      (reinterpret_cast<uintptr_t>(partials) & 7u) || (reinterpret_cast<uintptr_t>(spot_g) & 7u))
+      (reinterpret_cast<uintptr_t>(partials) & 7u) || (reinterpret_cast<uintptr_t>(spot_mom) & 7u))
     return RTT_E_ALIGN;
   bool any_sensor;
   int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
   if (rc != RTT_OK) return rc;
-  if (spot_slot >= RTT_MAX_SURFACES || (spot_slot >= 0 && !(wsum > 0.0))) return RTT_E_SIZE;
+  if (spot_slot >= RTT_MAX_SURFACES || (spot_slot >= 0 && !spot_mom && (!(wsum > 0.0) || spot_centroid))) return RTT_E_SIZE;
   AccMap am = {};
   int n_acc = 0;
   for (int s = 0; s < n_surf; ++s) {
@@ -2600,8 +2610,8 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   if (blocks > kAdjMaxBlocks) blocks = kAdjMaxBlocks;
   if (n_acc > 0 && blocks > partial_rows) return RTT_E_SIZE;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
-  AdjointIO a = {adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, spot_slot, (float)cx, (float)cy,
-                 spot_slot >= 0 ? (float)(1.0 / wsum) : 0.0f, spot_g, ray_adj, ld_ray, partials, n_acc};
+  AdjointIO a = {adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, spot_slot, spot_centroid, (float)cx, (float)cy,
+                 (spot_slot >= 0 && !spot_mom) ? (float)(1.0 / wsum) : 0.0f, spot_mom, ray_adj, ld_ray, partials, n_acc};
   const Ops ops = make_ops(prog_host, n_surf);
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) && aligned8(adj_pos) &&
@@ -2630,15 +2640,16 @@ int64_t rtt_trace_seq_adjoint_workspace_bytes(int n_slots) {
 int rtt_trace_seq_adjoint_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
                               const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
                               const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
-                              int spot_slot, double cx, double cy, double wsum, const double* spot_g, float* ray_adj,
-                              int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes, void* stream) {
+                              int spot_slot, int spot_centroid, double cx, double cy, double wsum, const double* spot_mom,
+                              float* ray_adj, int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
   int n_acc = 0;
   if (slot_mask && n_surf >= 1 && n_surf <= RTT_MAX_SURFACES)
     for (int s = 0; s < n_surf; ++s) n_acc += __builtin_popcount(slot_mask[s]);
   const int64_t rows = n_acc > 0 ? workspace_bytes / ((int64_t)sizeof(double) * n_acc) : 0;
   return trace_seq_adjoint(pos_in, dir_in, inten_in, ld_in, n, prog_dev, prog_host, n_surf, slot_mask, adj_pos, adj_dir, ld_adj,
-                           adj_sens, sens_ld, spot_slot, cx, cy, wsum, spot_g, ray_adj, ld_ray, slot_adj, (double*)workspace, rows,
-                           (hipStream_t)stream);
+                           adj_sens, sens_ld, spot_slot, spot_centroid, cx, cy, wsum, spot_mom, ray_adj, ld_ray, slot_adj,
+                           (double*)workspace, rows, (hipStream_t)stream);
 }
 
 int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, const RttSurface* prog_dev,
@@ -2740,7 +2751,7 @@ static int moments_grid(int64_t n) {
 int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const uint8_t* mask, int64_t n, int pass,
                          double cx, double cy, double wsum, double* out, void* stream) {
   if (!x || !y || !w || !out) return RTT_E_NULL;
-  if (n < 0 || pass < 0 || pass > 2) return RTT_E_SIZE;
+  if (n < 0 || pass < 0 || pass > 4) return RTT_E_SIZE;
   if (misaligned(x) || misaligned(y) || misaligned(w) || (reinterpret_cast<uintptr_t>(out) & 7u)) return RTT_E_ALIGN;
   if (n == 0) return RTT_OK;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

@@ -265,8 +265,8 @@ def spot_moments(x, y, w, mask, pass_id: int, cx: float, cy: float, wsum: float,
     """Accumulate spot-size moments into `out` (4 float64 on the device)."""
     N.require_device(x, y, w, out)
     n = x.numel()
-    if out.dtype != torch.float64 or out.numel() != (6 if pass_id == 2 else 4) or not out.is_contiguous():
-        raise ValueError("`out` must be 4 float64 values (6 for pass 2)")
+    if out.dtype != torch.float64 or out.numel() not in ((6,) if pass_id >= 2 else (4, 6)) or not out.is_contiguous():
+        raise ValueError("`out` must be 4 or 6 float64 values (6 for the passes that also sum the centroid term)")
     for t in (x, y, w):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
             raise ValueError("x, y, w must be contiguous float32 tensors of equal length")

@@ -122,8 +122,8 @@ class SpotSizeLoss(Goal):
 
     def _fused(self, scene, rays, tgt):
         """Trainable sequential scene whose sensor is visited once: trace without a graph and attach the
-        single fused backward.  Returns the loss, False when nothing lit reached the sensor, or None when
-        the fused form does not apply."""
+        single fused backward.  Returns (loss, lit) — `lit` a 0/1 device tensor, 0 when nothing lit reached the
+        sensor — or None when the fused form does not apply."""
         from .. import autograd as AG
         from .. import kernels as K
         from .. import program as P
@@ -144,9 +144,9 @@ class SpotSizeLoss(Goal):
         k = slots[0]
         # the host work of the backward's set-up (parameter list, slot Jacobians) runs while the device traces;
         # "nothing lit reached the sensor" (optim/goals.py:165-167) is read off the first moment, W = 0
-        loss = AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
-                                  group=getattr(scene, "grad_group", None), params=scene._element_params()[1])
-        return False if loss is None else loss
+        return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
+                                  group=getattr(scene, "grad_group", None), params=scene._element_params()[1],
+                                  table_cache=(scene.__dict__, scene._prog_cache[0]))
 
     def _sensor_records(self):
         s = self.sensor
@@ -157,7 +157,7 @@ class SpotSizeLoss(Goal):
 
     def forward(self, scene) -> torch.Tensor:
         from ..scene import SequentialScene
-        losses = []
+        losses, counted = [], []   # per bundle: the loss, and None (counts) or a 0/1 device tensor (counts when lit)
         for i, bundle in enumerate(self.bundles):
             self.sensor.reset()
             rays = bundle.sample(self.N_rays)
@@ -172,8 +172,10 @@ class SpotSizeLoss(Goal):
             if isinstance(scene, SequentialScene):
                 fused = self._fused(scene, rays, tgt)
                 if fused is not None:
-                    if fused is not False:
-                        losses.append(fused)
+                    # whether anything lit reached the sensor is known on the device only; the bundle is weighed by
+                    # that flag below instead of being skipped here, which would cost a host round trip per bundle
+                    losses.append(fused[0])
+                    counted.append(fused[1])
                     continue
                 scene.simulate(rays)   # the reference's no-argument call only works on Scene
             else:
@@ -191,6 +193,11 @@ class SpotSizeLoss(Goal):
             loss = spot_size_from_records(recs, tgt, group=group, device=dev)
             if loss is not None:
                 losses.append(loss)
+                counted.append(None)
         if not losses:
             return torch.tensor(0.0)
-        return torch.stack(losses).mean()
+        if all(c is None for c in counted):
+            return torch.stack(losses).mean()
+        # mean over the bundles that were lit (optim/goals.py:165-167, :185-187); 0 when none was
+        flags = torch.stack([torch.ones((), device=l.device) if c is None else c.to(l.device) for l, c in zip(losses, counted)])
+        return (torch.stack(losses) * flags).sum() / flags.sum().clamp_min(1.0)

@@ -73,13 +73,13 @@ def test_entry_points_validate_before_touching_the_gpu():
     assert lib.rtt_ray_cast_f32(p, p, 8, 0, p, hp, 1, 0, 0, 0) == 0
     assert lib.rtt_intersect_test_f32(p, p, 8, 8, p, hp, 1, 0, 8, 0) == E_NULL
     assert lib.rtt_surface_forward_f32(p, p, 8, 8, p, hp, 64, 0, 0, 0, 0, 0, 0, 8, 0) == E_SIZE
-    assert lib.rtt_spot_moments_f32(p, p, p, 0, 8, 3, 0.0, 0.0, 1.0, p, 0) == E_SIZE
+    assert lib.rtt_spot_moments_f32(p, p, p, 0, 8, 5, 0.0, 0.0, 1.0, p, 0) == E_SIZE
     # reverse-mode backward: host program required, slot budget, workspace rows
     mask = (ctypes.c_uint32 * 1)(0x07000000)   # geom 0-2 of the single surface
     mp = ctypes.addressof(mask)
     adj = lambda **kw: lib.rtt_trace_seq_adjoint_f32(*[kw.get(k, v) for k, v in (
         ("pos", p), ("dir", p), ("inten", p), ("ld", 8), ("n", 8), ("dev", p), ("host", hp), ("n_surf", 1), ("mask", mp),
-        ("adj_pos", p), ("adj_dir", 0), ("ld_adj", 8), ("adj_sens", 0), ("sens_ld", 0), ("spot", -1), ("cx", 0.0), ("cy", 0.0),
+        ("adj_pos", p), ("adj_dir", 0), ("ld_adj", 8), ("adj_sens", 0), ("sens_ld", 0), ("spot", -1), ("centroid", 0), ("cx", 0.0), ("cy", 0.0),
         ("wsum", 1.0), ("spot_g", 0), ("ray_adj", 0), ("ld_ray", 0), ("out", p), ("ws", p), ("ws_bytes", 1 << 20), ("stream", 0))])
     assert adj(host=0) == E_NULL
     assert adj(ld_adj=4) == E_SIZE
@@ -88,11 +88,11 @@ def test_entry_points_validate_before_touching_the_gpu():
     assert adj(spot=0, wsum=0.0) == E_SIZE
     full = (ctypes.c_uint32 * 64)(*([0xFFFFFFFF] * 64))
     # all 32 slots of the one surface: accepted as a request, refused for its workspace
-    assert lib.rtt_trace_seq_adjoint_f32(p, p, p, 8, 8, p, hp, 1, ctypes.addressof(full), p, 0, 8, 0, 0, -1, 0.0, 0.0, 1.0, 0, 0, 0,
+    assert lib.rtt_trace_seq_adjoint_f32(p, p, p, 8, 8, p, hp, 1, ctypes.addressof(full), p, 0, 8, 0, 0, -1, 0, 0.0, 0.0, 1.0, 0, 0, 0,
                                          p, p, 16, 0) == E_SIZE
     assert adj(n=0, mask=0) == 0
-    assert lib.rtt_trace_seq_adjoint_max_slots(4) == 128 and lib.rtt_trace_seq_adjoint_max_slots(30) == 40
-    assert lib.rtt_trace_seq_adjoint_max_slots(40) == 0 and lib.rtt_trace_seq_adjoint_max_slots(0) == 0
+    assert lib.rtt_trace_seq_adjoint_max_slots(4) == 128 and lib.rtt_trace_seq_adjoint_max_slots(20) == 20
+    assert lib.rtt_trace_seq_adjoint_max_slots(23) == 0 and lib.rtt_trace_seq_adjoint_max_slots(0) == 0
     assert lib.rtt_trace_seq_adjoint_workspace_bytes(10) == 8 * 2048 * 10
     # differentiable bounce loop: host copy of the program required, n_theta in {2,4,6,8}, ray seeds need >= 6
     args = lambda hp_, k, seed: (p, p, p, 8, p, p, p, 8, 8, p, hp_, 1, 3, p, k, seed, p, p, p, p, p, 8, 0)

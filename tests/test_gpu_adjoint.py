@@ -119,15 +119,15 @@ def _many_singlets(ns, count):
     return els + [ns.Sensor(ns.Disk(20.0, transform=ns.RayTransform(translation=[0.0, 0.0, 3.0 * count + 2.0])))]
 
 
-@pytest.mark.parametrize("count,launches", [(10, "several"), (13, None)])
+@pytest.mark.parametrize("count,launches", [(6, "several"), (8, None)])
 def test_slot_budget_edges(ns, count, launches, monkeypatch):
-    """31 surfaces leave room for 36 slot accumulators per launch, fewer than the wanted slots of ten trainable
-    singlets, which therefore take several launches; 40 surfaces leave none and the forward-mode kernels take over."""
+    """19 surfaces leave room for 27 slot accumulators per launch, fewer than the wanted slots of six trainable
+    singlets, which therefore take several launches; 25 surfaces leave none and the forward-mode kernels take over."""
     def build():
         return _many_singlets(ns, count), scenes.disk_bundle(ns, radius=3.0, z=-10.0).sample(3001).to(DEV)
     n_surf = 3 * count + 1
     budget = N.lib().rtt_trace_seq_adjoint_max_slots(n_surf)
-    assert budget == max(0, 160 - 4 * n_surf)
+    assert budget == max(0, 160 - 7 * n_surf)
     calls = []
     obj_a, ga = _grads(ns, build, _projection(ns, 1), "adjoint", monkeypatch, calls)
     obj_t, gt = _grads(ns, build, _projection(ns, 1), "tangent", monkeypatch)
@@ -164,7 +164,7 @@ def test_entry_point_directly(ns):
         ws = torch.empty(int(lib.rtt_trace_seq_adjoint_workspace_bytes(len(pairs))), dtype=torch.uint8, device=DEV)
         code = lib.rtt_trace_seq_adjoint_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev),
                                              dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
-                                             -1, 0.0, 0.0, 1.0, 0, N.ptr(ray_adj), n, N.ptr(slot_adj), N.ptr(ws), ws.numel(),
+                                             -1, 0, 0.0, 0.0, 1.0, 0, N.ptr(ray_adj), n, N.ptr(slot_adj), N.ptr(ws), ws.numel(),
                                              N.stream_handle(DEV))
         N.check(code, "rtt_trace_seq_adjoint_f32")
         outs.append((slot_adj.cpu(), ray_adj.cpu()))
@@ -183,7 +183,7 @@ def test_entry_point_directly(ns):
         slot_adj = torch.empty(len(pairs), dtype=torch.float64, device=DEV)
         code = lib.rtt_trace_seq_adjoint_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev),
                                              dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
-                                             -1, 0.0, 0.0, 1.0, 0, 0, 0, N.ptr(slot_adj), N.ptr(ws), ws.numel(), N.stream_handle(DEV))
+                                             -1, 0, 0.0, 0.0, 1.0, 0, 0, 0, N.ptr(slot_adj), N.ptr(ws), ws.numel(), N.stream_handle(DEV))
         N.check(code, "rtt_trace_seq_adjoint_f32")
         assert float((slot_adj.cpu() - outs[0][0]).abs().max()) <= 1e-5 * scale
     finally:
