@@ -198,6 +198,20 @@ int rtt_trace_seq_adjoint_f32(const float* pos_in, const float* dir_in, const fl
                               float* ray_adj, int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes,
                               void* stream);
 
+/* The same backward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  Identical to rtt_trace_seq_adjoint_f32 in
+ * arguments (without the workspace) and in results, bit for bit; the per-block sums go to a static device array of the
+ * library (2 MiB = 2048 blocks x 128 slot sums of float64 per GPU, held until the process ends) instead of a caller's
+ * workspace.  At most 128 set bits in slot_mask (RTT_E_SIZE beyond).  Neither this call nor anything it calls
+ * allocates or frees.  All calls on one GPU share that array: calls that overlap in time on one GPU (different
+ * streams, different threads) race on it and must be serialised by the caller; calls on different GPUs are independent. */
+int rtt_trace_seq_adjoint_static_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                                     const uint32_t* slot_mask, const float* adj_pos, const float* adj_dir, int64_t ld_adj,
+                                     const float* adj_sens, int64_t sens_ld, int spot_slot, int spot_centroid, double cx, double cy,
+                                     double wsum, const double* spot_mom, float* ray_adj, int64_t ld_ray, double* slot_adj,
+                                     void* stream);
+
 /* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
  * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
  * tmin[i] = that t.  Either output may be NULL. */

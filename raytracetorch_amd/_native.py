@@ -33,6 +33,8 @@ _SIGNATURES = {
                                     _vp, _vp],
     "rtt_trace_seq_adjoint_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
                                   _int, _int, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
+    "rtt_trace_seq_adjoint_static_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
+                                         _int, _int, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp],
     "rtt_ray_cast_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp],
     "rtt_step_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                              _vp, _vp, _vp, _vp, _i64, _vp],

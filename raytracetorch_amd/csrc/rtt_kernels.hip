@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -2625,7 +2626,47 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
 
 }  // namespace
 
+// Block-sum scratch of rtt_trace_seq_adjoint_static_f32: one array per GPU the library runs on, held until the process
+// ends.  In host code the name below is only a handle for hipGetSymbolAddress; kernels get the address it returns.
+static __device__ __align__(256) double scratch[(size_t)kAdjMaxBlocks * kAdjMaxAcc];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::atomic<double*> g_scratch_ptr[kMaxDevices];
+
+// Address of `scratch` on the current device, looked up once per device (each GPU holds its own copy at its own address).
+double* scratch_on_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  double* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p) return p;
+  void* addr = nullptr;
+  if (hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch)) != hipSuccess || !addr) return nullptr;
+  g_scratch_ptr[dev].store(static_cast<double*>(addr), std::memory_order_release);
+  return static_cast<double*>(addr);
+}
+
+}  // namespace
+
 extern "C" {
+
+int rtt_trace_seq_adjoint_static_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
+                                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                                     const uint32_t* slot_mask, const float* adj_pos, const float* adj_dir, int64_t ld_adj,
+                                     const float* adj_sens, int64_t sens_ld, int spot_slot, int spot_centroid, double cx, double cy,
+                                     double wsum, const double* spot_mom, float* ray_adj, int64_t ld_ray, double* slot_adj,
+                                     void* stream) {
+  int n_acc = 0;
+  if (slot_mask && n_surf >= 1 && n_surf <= RTT_MAX_SURFACES)
+    for (int s = 0; s < n_surf; ++s) n_acc += __builtin_popcount(slot_mask[s]);
+  if (n_acc > kAdjMaxAcc) return RTT_E_SIZE;  // more slot sums than the static scratch has columns for
+  double* partials = scratch_on_current_device();
+  if (!partials) return RTT_E_LAUNCH;
+  return trace_seq_adjoint(pos_in, dir_in, inten_in, ld_in, n, prog_dev, prog_host, n_surf, slot_mask, adj_pos, adj_dir, ld_adj,
+                           adj_sens, sens_ld, spot_slot, spot_centroid, cx, cy, wsum, spot_mom, ray_adj, ld_ray, slot_adj, partials,
+                           kAdjMaxBlocks, (hipStream_t)stream);
+}
 
 int rtt_trace_seq_adjoint_max_slots(int n_surf) {
   if (n_surf < 1 || n_surf > RTT_MAX_SURFACES) return 0;
