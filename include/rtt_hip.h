@@ -120,6 +120,18 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
                       float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
                       void* stream);
 
+/* The same trace, and beside it the first spot-size moments of one sensor slot (optim/goals.py:165-178 right behind
+ * scene/sequential.py:12-36): mom[0..2] = sum w, sum w x, sum w y over the hits recorded on slot mom_slot with intensity
+ * w > 0, overwritten.  The sums are formed while the hit is in registers (float32 per wavefront, float64 from there on),
+ * which saves the pass of rtt_spot_moments_f32 (pass 0) over the record.  workspace: device scratch of
+ * rtt_trace_seq_moments_workspace_bytes(n) bytes for the per-block sums.  The sensor buffers and prog_host are required. */
+int64_t rtt_trace_seq_moments_workspace_bytes(int64_t n);
+int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                              float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
+                              int mom_slot, double* mom, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- the same trace with per-surface position snapshots: SequentialScene.simulate on rays wrapped in Paths
  * (rays/ray.py:100-207; Paths.scatter_update :174-185 snapshots every ray's position after each surface that
  * was hit by at least one ray).  hist_pos[(3*s + c)*hist_ld + i] receives component c of ray i after surface s,

@@ -25,6 +25,8 @@ _dbl = ctypes.c_double
 _SIGNATURES = {
     "rtt_trace_seq_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                           _vp, _vp, _vp, _i64, _vp],
+    "rtt_trace_seq_moments_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
+                                  _vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _vp],
     "rtt_trace_seq_history_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                                   _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
     "rtt_trace_seq_tangent_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _int, _vp, _vp, _i64, _vp, _i64,
@@ -54,7 +56,8 @@ _SIGNATURES = {
     "rtt_sample_bundle_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
 }
 EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune",
-                                "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes")
+                                "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes",
+                                "rtt_trace_seq_moments_workspace_bytes")
 
 
 class RttSource(ctypes.Structure):
@@ -96,6 +99,8 @@ def lib():
     L.rtt_trace_seq_adjoint_max_slots.restype = _int
     L.rtt_trace_seq_adjoint_workspace_bytes.argtypes = [_int]
     L.rtt_trace_seq_adjoint_workspace_bytes.restype = _i64
+    L.rtt_trace_seq_moments_workspace_bytes.argtypes = [_i64]
+    L.rtt_trace_seq_moments_workspace_bytes.restype = _i64
     if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
         raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")
     _lib = L

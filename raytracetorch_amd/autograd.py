@@ -539,6 +539,9 @@ def _assemble_grads(dtheta, thetas, param_meta, param_ids, derived=None):
         flat = torch.zeros(int(starts[-1]), dtype=torch.float64)
         if dst:
             flat[torch.tensor(dst, dtype=torch.int64)] = dtheta.cpu()
+    if param_meta and all(dt == param_meta[0][1] and dev == flat.device for _, dt, dev in param_meta):
+        flat = flat.to(param_meta[0][1])   # one conversion; the gradients are views of it
+        return [flat[starts[k]:starts[k + 1]].reshape(shape) for k, (shape, _, _) in enumerate(param_meta)]
     return [flat[starts[k]:starts[k + 1]].reshape(shape).to(device=dev, dtype=dt)
             for k, (shape, dt, dev) in enumerate(param_meta)]
 
@@ -577,9 +580,10 @@ class FusedSpotLossFn(torch.autograd.Function):
             dtheta, _ = _adjoint_sweep(rays_in, prog, table, spot=(sensor_slot, centroid, tx, ty, mom), derived=derived)
             allreduce_sum_(dtheta, group)
             ctx.dtheta = dtheta
-            lit = (mom[0] > 0).to(torch.float32)
+            out = mom.to(torch.float32)   # one conversion: the loss and the lit weight are views of it
+            lit = out[0].sign()
             ctx.mark_non_differentiable(lit)
-            return mom[3].to(torch.float32), lit
+            return out[3], lit
         # everything the tangent launches need that does not depend on the centroid goes to the device now, while it
         # is still busy with the trace and the first moments: after the synchronisation below only launches remain
         dp = _tangent_program(prog, table, dev) if n else None
@@ -649,16 +653,18 @@ def _cached_scalars(elements, params=None):
     return hit[2]
 
 
-def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None, params=None, table_cache=None):
+def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=None, params=None, table_cache=None,
+                    mom=None):
     """Differentiable spot-size loss of a bundle already traced (forward only, no graph) through `prog`;
     `sens` = (hit [3,N], w [N], mask [N]) of the sensor slot, `rays` the *input* bundle of that trace.
     Returns (loss, lit): `lit` is a 0/1 tensor on the device, 0 when nothing lit reached the sensor on any rank (the
     reference skips such a bundle, optim/goals.py:165-167; the loss is then 0 with zero gradients).  Neither is read
     on the host here, so the caller's step stays asynchronous."""
     hit, w, mask = sens
-    # first moments right behind the trace; the host work below overlaps both kernels
-    mom = torch.zeros(6, device=w.device, dtype=torch.float64)
-    _spot_moments(hit[0], hit[1], w, mask, 0, 0.0, 0.0, 1.0, mom)
+    if mom is None:   # (a caller whose trace already summed the first moments hands them in: six float64, three filled)
+        # first moments right behind the trace; the host work below overlaps both kernels
+        mom = torch.zeros(6, device=w.device, dtype=torch.float64)
+        _spot_moments(hit[0], hit[1], w, mask, 0, 0.0, 0.0, 1.0, mom)
     thetas = _cached_scalars(elements, params)
     # `table_cache` = (dict owned by the scene, key of the scene's parameter state): the slot Jacobians are derived
     # again only when a parameter changed (for device-resident parameters deriving them costs a device-to-host

@@ -49,9 +49,6 @@ struct AdjointIO {
   int n_acc;
 };
 
-DI float hsum(float v) { return v; }
-DI float hsum(f2 v) { return v.x + v.y; }
-
 template <class T>
 struct SlotSink {
   float* acc;     // this lane's column of the accumulators: accumulator a lives at acc[a * kBlock]
@@ -270,16 +267,16 @@ DI void root_adjoint(const RecF& S, V3<T> o, V3<T> d, T t, V3<T> h, T tb, V3<T>&
       const float c = S.geom(0), c1k = S.geom(2);
       const float kx = C::sk(S.r) == RTT_SURF_QUADRIC ? 1.0f : 0.0f;
       const T A = c * (kx * d.x * d.x + d.y * d.y) + c1k * (d.z * d.z);
-      const T B = 2.0f * c * (kx * o.x * d.x + o.y * d.y) + 2.0f * c1k * o.z * d.z - 2.0f * d.z;
       go = {2.0f * c * kx * h.x, 2.0f * c * h.y, 2.0f * c1k * h.z - 2.0f};
       i0 = 0;
       i1 = 2;
       gd = scale(t, go);
       g0 = kx * h.x * h.x + h.y * h.y;
       g1 = h.z * h.z;
-      den = 2.0f * A * t + B;
+      den = dot3(go, d);  // 2 A t + B: the derivative of the surface equation along the ray, grad F(h) . d
       const auto lin = lt(abs_(A), eps);  // the reference's linear root -C / B_safe: the A term is dropped
       if (__any(any_(lin))) {
+        const T B = 2.0f * c * (kx * o.x * d.x + o.y * d.y) + 2.0f * c1k * o.z * d.z - 2.0f * d.z;
         const V3<T> gd_lin = {t * (2.0f * c * kx) * o.x, t * (2.0f * c) * o.y, t * (2.0f * c1k * o.z - 2.0f)};
         gd = sel3(lin, gd_lin, gd);
         g0 = sel(lin, 2.0f * t * (kx * o.x * d.x + o.y * d.y) + (kx * o.x * o.x + o.y * o.y), g0);
@@ -573,18 +570,18 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
     for (int j = 0; j < kBlock / 64; ++j) v += (double)col[lane + 64 * j];
     v = wave_sum(v);
-    if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;
+    if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;  // read back by k_sum_partials with strides (n_acc, 1)
   }
 }
 
-// out[k] = sum over blocks of partials[b][k]; one block per accumulator, fixed order: the result does not depend on
-// the order in which the blocks of the first kernel finished
-__global__ void __launch_bounds__(kBlock) k_sum_partials(const double* __restrict__ partials, int n_blocks, int n_acc,
-                                                         double* __restrict__ out) {
+// out[k] = sum over blocks b of partials[b * stride_b + k * stride_k]; one block per accumulator, fixed order: the
+// result does not depend on the order in which the blocks of the first kernel finished
+__global__ void __launch_bounds__(kBlock) k_sum_partials(const double* __restrict__ partials, int n_blocks, int64_t stride_b,
+                                                         int64_t stride_k, double* __restrict__ out) {
   __shared__ double part[kBlock / 64];
   const int k = blockIdx.x;
   double v = 0.0;
-  for (int b = threadIdx.x; b < n_blocks; b += kBlock) v += partials[(int64_t)b * n_acc + k];
+  for (int b = threadIdx.x; b < n_blocks; b += kBlock) v += partials[(int64_t)b * stride_b + (int64_t)k * stride_k];
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) part[wv] = v;

@@ -934,7 +934,13 @@ struct SensorIO {
   int32_t* app_key;    // [cap][2]: bounce * RTT_MAX_SURFACES + sensor slot, index of the ray in the call
   int32_t* app_count;  // number of hits offered so far (may exceed cap: the host then retries with more room)
   int32_t app_cap, bounce;
+  // first spot moments on the side (dense mode): lane_mom[0..2] += w, w x, w y of the lane's lit hits on slot mom_slot
+  float* lane_mom;
+  int32_t mom_slot;
 };
+
+DI float hsum(float v) { return v; }
+DI float hsum(f2 v) { return v.x + v.y; }
 
 template <class T>
 struct Ray {
@@ -1018,6 +1024,16 @@ DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, 
     }
     return;
   }
+  if (se.lane_mom && slot == se.mom_slot) {  // SpotSizeLoss's W, sum w x, sum w y (optim/goals.py:165-178) while the hit is in registers
+    auto lit = and_(hit, gt(I, splat<T>(0.0f)));
+#pragma unroll
+    for (int k = 0; k < LaneOf<T>::N; ++k)
+      if (k >= nv) lit = set_mask(lit, k, false);
+    const T wm = sel(lit, I, splat<T>(0.0f));
+    se.lane_mom[0] += hsum(wm);
+    se.lane_mom[1] += hsum(wm * sel(lit, hl.x, splat<T>(0.0f)));
+    se.lane_mom[2] += hsum(wm * sel(lit, hl.y, splat<T>(0.0f)));
+  }
   const int64_t base = (int64_t)slot * se.ld;  // wave-uniform: the slot's planes are addressed by pointer
   uint8_t* mask = se.mask + base;
   float* hx = se.hit + 3 * base;
@@ -1078,10 +1094,14 @@ DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, I i, int nv) {
 // bundle, goes through the same packed arithmetic, so a ray's result does not depend on the size or
 // alignment of the batch it is traced in.
 // ------------------------------------------------------------------------------------------------
-template <class T, int G, bool LDS_PROG>
+// MOM: the first spot moments of sensor slot se.mom_slot are summed on the way (float per wavefront, float64 from
+// there on) and each block stores its three sums to mom_partials[k * gridDim.x + blockIdx.x].
+template <class T, int G, bool LDS_PROG, bool MOM = false>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                      Ops ops, SensorIO se, int vec) {
+                                                      Ops ops, SensorIO se, int vec, double* __restrict__ mom_partials = nullptr) {
   __shared__ RttSurface lds_prog[LDS_PROG ? RTT_MAX_SURFACES : 1];
+  __shared__ double mom_wave[MOM ? 3 * (kBlock / 64) : 1];
+  float lane_mom[3] = {0.0f, 0.0f, 0.0f};
   if (LDS_PROG) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(prog_);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds_prog);
@@ -1099,8 +1119,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
     // the tile's planes are addressed from wave-uniform base pointers with 32-bit lane offsets
     const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in,
                        io.pos_out + base, io.dir_out + base, io.inten_out + base, io.ld_out, io.n - base};
-    const SensorIO tse = {se.hit ? se.hit + base : nullptr, se.w ? se.w + base : nullptr,
-                          se.mask ? se.mask + base : nullptr, se.ld, base};
+    SensorIO tse = {se.hit ? se.hit + base : nullptr, se.w ? se.w + base : nullptr,
+                    se.mask ? se.mask + base : nullptr, se.ld, base};
+    tse.lane_mom = MOM ? lane_mom : nullptr;
+    tse.mom_slot = se.mom_slot;
     Ray<T> r[G];
     uint32_t idx[G];
     int nv[G];
@@ -1136,6 +1158,21 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
       } else if (nv[g]) {
         store_ray<T>(tio, idx[g], r[g], vec != 0, nv[g]);
       }
+    }
+  }
+  if (MOM) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = lane_mom[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) mom_wave[k * (kBlock / 64) + wv] = (double)v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      double sum = 0.0;
+      for (int w = 0; w < kBlock / 64; ++w) sum += mom_wave[threadIdx.x * (kBlock / 64) + w];
+      mom_partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
     }
   }
 }
@@ -2443,6 +2480,46 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
   return launch_status();
 }
 
+int64_t rtt_trace_seq_moments_workspace_bytes(int64_t n) {
+  return n < 0 ? 0 : (int64_t)sizeof(double) * 3 * grid_for(n, 2);
+}
+
+int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, float* sens_hit,
+                              float* sens_w, uint8_t* sens_mask, int64_t sens_ld, int mom_slot, double* mom, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host || !sens_hit || !sens_w ||
+      !sens_mask || !mom || !workspace)
+    return RTT_E_NULL;
+  if (n < 0 || ld_in < n || ld_out < n || sens_ld < n || mom_slot < 0 || mom_slot >= RTT_MAX_SURFACES) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out) || misaligned(sens_hit) || misaligned(sens_w) || (reinterpret_cast<uintptr_t>(mom) & 7u) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 7u))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int n_slots = 0;
+  int rc = check_program(prog_host, n_surf, &any_sensor, &n_slots);
+  if (rc != RTT_OK) return rc;
+  if (mom_slot >= n_slots) return RTT_E_SIZE;
+  const hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return hipMemsetAsync(mom, 0, 3 * sizeof(double), st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
+  const int blocks = grid_for(n, 2);
+  if (workspace_bytes < (int64_t)sizeof(double) * 3 * blocks) return RTT_E_SIZE;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+  SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
+  se.mom_slot = mom_slot;
+  const Ops ops = make_ops(prog_host, n_surf);
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
+                  aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+  hipLaunchKernelGGL((k_trace_seq<f2, 1, false, true>), dim3(blocks), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec,
+                     (double*)workspace);
+  if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
+  hipLaunchKernelGGL(k_sum_partials, dim3(3), dim3(kBlock), 0, st, (const double*)workspace, blocks, (int64_t)1, (int64_t)blocks, mom);
+  return launch_status();
+}
+
 }  // extern "C"
 
 namespace {
@@ -2620,7 +2697,7 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   rc = lanes == 2 ? launch_adjoint<f2>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
                   : launch_adjoint<float>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
   if (rc != RTT_OK || n_acc == 0) return rc;
-  hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, n_acc, slot_adj);
+  hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, (int64_t)n_acc, (int64_t)1, slot_adj);
   return launch_status();
 }
 

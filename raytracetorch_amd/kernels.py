@@ -33,9 +33,11 @@ def _sensor_buffers(prog, n, device):
     return hit, w, mask
 
 
-def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None):
+def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=None):
     """SequentialScene.simulate on the device.  Writes into `out` (default: in place into `rays`).
-    Returns (sens_hit [K,3,N], sens_w [K,N], sens_mask [K,N] uint8) or (None, None, None)."""
+    Returns (sens_hit [K,3,N], sens_w [K,N], sens_mask [K,N] uint8) or (None, None, None).
+    `moments` = (sensor slot, float64 device tensor of at least 3 entries): the same launch also leaves the first
+    spot-size moments (sum w, sum w x, sum w y over the lit hits of that slot) in the tensor's first three entries."""
     n = _check_rays(rays)
     if out is None:
         out = rays
@@ -46,8 +48,25 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None):
     if n == 0 or prog.shape[0] == 0:
         if out is not rays:
             out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
+        if moments is not None:
+            moments[1][:3] = 0.0
         return sens_hit, sens_w, sens_mask
     dp = N.DeviceProgram.upload(prog, dev)
+    if moments is not None:
+        slot, mom = moments
+        if mom.dtype != torch.float64 or mom.numel() < 3 or not mom.is_contiguous() or mom.device != dev:
+            raise ValueError("`moments` needs a contiguous float64 tensor of at least 3 entries on the rays' device")
+        ws_bytes = int(N.lib().rtt_trace_seq_moments_workspace_bytes(n))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            code = N.lib().rtt_trace_seq_moments_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+                N.ptr(out._pos), N.ptr(out._dir), N.ptr(out.intensity), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n,
+                N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, int(slot), N.ptr(mom), N.ptr(ws), ws_bytes,
+                N.stream_handle(dev))
+        N.check(code, "rtt_trace_seq_moments_f32")
+        return sens_hit, sens_w, sens_mask
     with torch.cuda.device(dev):
         code = N.lib().rtt_trace_seq_f32(
             N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,

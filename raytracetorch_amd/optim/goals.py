@@ -138,15 +138,17 @@ class SpotSizeLoss(Goal):
         src = Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id, rays.wavelength)
         out = Rays.from_planes(torch.empty_like(src._pos), torch.empty_like(src._dir), torch.empty_like(src.intensity),
                                rays.id, rays.wavelength)
-        hit, w, mask = K.trace_sequential(src, prog, out=out)
+        k = slots[0]
+        # the trace leaves the first moments of the sensor's hits (W, sum w x, sum w y) beside the record
+        mom = torch.zeros(6, device=src.device, dtype=torch.float64)
+        hit, w, mask = K.trace_sequential(src, prog, out=out, moments=(k, mom))
         scene._deliver_sensor_records(prog, src, hit, w, mask)
         rays._pos, rays._dir, rays.intensity = out._pos, out._dir, out.intensity
-        k = slots[0]
         # the host work of the backward's set-up (parameter list, slot Jacobians) runs while the device traces;
         # "nothing lit reached the sensor" (optim/goals.py:165-167) is read off the first moment, W = 0
         return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,
                                   group=getattr(scene, "grad_group", None), params=scene._element_params()[1],
-                                  table_cache=(scene.__dict__, scene._prog_cache[0]))
+                                  table_cache=(scene.__dict__, scene._prog_cache[0]), mom=mom)
 
     def _sensor_records(self):
         s = self.sensor
@@ -196,6 +198,8 @@ class SpotSizeLoss(Goal):
                 counted.append(None)
         if not losses:
             return torch.tensor(0.0)
+        if len(losses) == 1 and counted[0] is not None:
+            return losses[0]   # an unlit bundle's loss is 0 with zero gradients: the mean over "the lit ones" is the same number
         if all(c is None for c in counted):
             return torch.stack(losses).mean()
         # mean over the bundles that were lit (optim/goals.py:165-167, :185-187); 0 when none was

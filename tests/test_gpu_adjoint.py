@@ -204,3 +204,36 @@ def test_forward_mode_still_reproduces_the_reference(ns, monkeypatch):
     got = dict(c1=s0.c.grad, c2=s1.c.grad, ior_glass=lens.ior_glass.grad)
     for k, v in got.items():
         assert abs(float(v) - float(g["g_" + k])) <= 2e-4 * abs(float(g["g_" + k])), k
+
+
+@pytest.mark.parametrize("n", [1, 511, 70001, 2 ** 20 + 3])
+def test_trace_with_moments_equals_trace_then_moment_pass(ns, n):
+    """rtt_trace_seq_moments_f32: rays and sensor record identical to the plain trace, and the three first moments
+    equal to the float64 moment pass over that record (they are summed in float32 within a wavefront)."""
+    import raytracetorch_amd.kernels as K
+    elements = scenes.system5(ns)
+    prog = P.compile_elements(elements)
+    rays = scenes.disk_bundle(ns, radius=4.0, z=-30.0, rot=[0.004, -0.003, 0.0]).sample(n).to(DEV)
+    rays.intensity = (torch.rand(n, device=DEV) > 0.1).float() * (0.5 + torch.rand(n, device=DEV))   # some rays dark
+    a, b = rays.clone(), rays.clone()
+    hit0, w0, m0 = K.trace_sequential(a, prog)
+    mom = torch.full((6,), 7.0, dtype=torch.float64, device=DEV)
+    hit1, w1, m1 = K.trace_sequential(b, prog, moments=(0, mom))
+    assert torch.equal(a._pos, b._pos) and torch.equal(a._dir, b._dir) and torch.equal(a.intensity, b.intensity)
+    assert torch.equal(m0, m1)
+    on = m0[0].bool()
+    assert torch.equal(hit0[0][:, on], hit1[0][:, on]) and torch.equal(w0[0][on], w1[0][on])
+    want = torch.zeros(4, dtype=torch.float64, device=DEV)
+    K.spot_moments(hit0[0][0].contiguous(), hit0[0][1].contiguous(), w0[0], m0[0], 0, 0.0, 0.0, 1.0, want)
+    got, want = mom[:3].cpu(), want[:3].cpu()
+    assert torch.equal(mom[3:].cpu(), torch.full((3,), 7.0, dtype=torch.float64))    # only the first three are written
+    scale = float(want[0]) * 4.0 + 1e-30      # |x|, |y| <= 4 on this sensor
+    assert float((got - want).abs().max()) <= 2e-6 * scale, (got, want)
+    lib = N.lib()
+    dp = N.DeviceProgram.upload(prog, DEV)
+    ws = torch.empty(int(lib.rtt_trace_seq_moments_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    args = lambda slot, ws_bytes: (N.ptr(a._pos), N.ptr(a._dir), N.ptr(a.intensity), n, N.ptr(b._pos), N.ptr(b._dir), N.ptr(b.intensity),
+                                   n, n, N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(hit1), N.ptr(w1), N.ptr(m1), n, slot, N.ptr(mom),
+                                   N.ptr(ws), ws_bytes, N.stream_handle(DEV))
+    assert lib.rtt_trace_seq_moments_f32(*args(1, ws.numel())) == -2     # the program has one sensor slot
+    assert lib.rtt_trace_seq_moments_f32(*args(0, ws.numel() - 8)) == -2  # workspace too small
