@@ -45,6 +45,9 @@ def parse():
                     help="singlet = the headline line; the others time the remaining configurations (informational)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two "
                                                       "ranks rehearse the multi-rank path on one GPU)")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with --gpus 1: still form a process group of one rank over --backend, so that the collective "
+                         "calls of the N > 1 path (RCCL barrier, all-reduce) execute on a one-GPU box")
     ap.add_argument("--step-loop", action="store_true",
                     help="naive_sim workload: one launch per bounce (the reference's loop) instead of the fused bounce loop")
     ap.add_argument("--graph", action="store_true",
@@ -55,6 +58,7 @@ def parse():
     ap.add_argument("--tune-reduce-blocks", type=int, default=0, help="override the grid of the reducing kernels (experiment)")
     ap.add_argument("--tune-cull", type=int, default=-1, help="0: nearest-hit kernels test every surface (experiment)")
     ap.add_argument("--tune-adjoint-lane", type=int, default=0, help="rays per lane of the reverse-mode backward: 1, 2, 0 = automatic")
+    ap.add_argument("--tune-adjoint-block", type=int, default=0, help="threads per block of the reverse-mode backward: 128 or 256")
     return ap.parse_args()
 
 
@@ -389,8 +393,10 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     dist = None
-    if world > 1:
+    if world > 1 or a.dist_single:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:   # (a single rank started by hand)
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -413,6 +419,8 @@ def main():
         _native.check(_native.lib().rtt_tune(3, a.tune_cull), "rtt_tune")
     if a.tune_adjoint_lane:
         _native.check(_native.lib().rtt_tune(6, a.tune_adjoint_lane), "rtt_tune")
+    if a.tune_adjoint_block:
+        _native.check(_native.lib().rtt_tune(7, a.tune_adjoint_block), "rtt_tune")
 
     if a.workload != "singlet":
         return other_workload(a, ns, scenes, dev, rank, world, dist)

@@ -126,7 +126,8 @@ def ptr(t):
 
 def stream_handle(device):
     """Raw handle of torch's current stream on `device` (the launch stream of every entry point)."""
-    device = torch.device(device)
+    if type(device) is not torch.device:
+        device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
     return torch._C._cuda_getCurrentRawStream(index)
 
@@ -145,8 +146,21 @@ class DeviceProgram:
     @classmethod
     def upload(cls, prog: np.ndarray, device, tag: str = "") -> "DeviceProgram":
         device = torch.device(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        facts = P.facts_of(prog)   # a program packed by a scene remembers its device copies
+        if facts is not None:
+            dp = facts.get(("device copy", index, tag))
+            if dp is not None:
+                return dp
+            dp = cls._upload(np.asarray(prog), device, index, tag)
+            facts[("device copy", index, tag)] = dp
+            return dp
+        return cls._upload(prog, device, index, tag)
+
+    @classmethod
+    def _upload(cls, prog, device, index, tag):
         prog = np.ascontiguousarray(prog)
-        key = (device.index if device.index is not None else torch.cuda.current_device(), prog.shape[0], tag)
+        key = (index, prog.shape[0], tag)
         raw = prog.tobytes()
         recent = cls._cache.setdefault(key, {})
         dp = recent.get(raw)
@@ -161,8 +175,11 @@ class DeviceProgram:
 
     @property
     def n(self):
-        return int(self.host.shape[0])
+        return self.host.shape[0]
 
     @property
     def host_ptr(self):
-        return self.host.ctypes.data
+        p = self.__dict__.get("_host_ptr")
+        if p is None:   # (numpy builds the ctypes view on every access)
+            p = self.__dict__["_host_ptr"] = self.host.ctypes.data
+        return p

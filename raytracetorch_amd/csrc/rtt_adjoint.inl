@@ -51,7 +51,8 @@ struct AdjointIO {
 
 template <class T>
 struct SlotSink {
-  float* acc;     // this lane's column of the accumulators: accumulator a lives at acc[a * kBlock]
+  float* acc;     // this lane's column of the accumulators: accumulator a lives at acc[a * stride]
+  int stride;     // threads per block
   uint32_t mask;  // wanted slots of the surface (wave-uniform)
   int base;
   typename LaneOf<T>::M on;  // components whose contribution counts: hit and part of the bundle
@@ -63,7 +64,7 @@ struct SlotSink {
     const int a = base + __builtin_popcount(mask & ((1u << slot) - 1u));
     const float x = all_on ? hsum(v) : hsum(sel(on, v, splat<T>(0.0f)));
     // the column belongs to this lane alone: a plain read-modify-write (an LDS atomic add measured slower)
-    acc[a * kBlock] += x;
+    acc[a * stride] += x;
   }
 };
 
@@ -416,18 +417,18 @@ template <class I> DI f2 ldp_(const float* p, I i, bool vec, int nv, f2*) {
   return f2{p[i], p[i + (nv - 1)]};
 }
 
-// dynamic LDS: float acc[n_acc][kBlock], then T state[n_surf][kAdjState][kBlock]
+// dynamic LDS: float acc[n_acc][BS], then T state[n_surf][kAdjState][BS]; BS threads per block
 // Two wavefronts per SIMD is what the LDS of a four-surface program allows with two rays per lane (three with one).
-template <class T>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+template <class T, int BS>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                               Ops ops, AccMap am, AdjointIO a, int vec) {
   extern __shared__ float lds_dyn[];
   constexpr int N = LaneOf<T>::N;
   using M = typename LaneOf<T>::M;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   float* acc = lds_dyn + threadIdx.x;
-  T* state = reinterpret_cast<T*>(lds_dyn + (int64_t)a.n_acc * kBlock) + threadIdx.x;
-  for (int k = 0; k < a.n_acc; ++k) acc[k * kBlock] = 0.0f;
+  T* state = reinterpret_cast<T*>(lds_dyn + (int64_t)a.n_acc * BS) + threadIdx.x;
+  for (int k = 0; k < a.n_acc; ++k) acc[k * BS] = 0.0f;
   float Gx = 0.0f, Gy = 0.0f, cx = a.cx, cy = a.cy, inv_w = a.inv_w;
   if (a.spot_slot >= 0 && a.spot_mom) {
     const double W = fmax(a.spot_mom[0], 1e-12);  // the reference clamps the weight sum (optim/goals.py:173)
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
       Gy = (float)a.spot_mom[5];
     }
   }
-  const int64_t tile = (int64_t)kBlock * N;
+  const int64_t tile = (int64_t)BS * N;
   const int64_t stride = (int64_t)gridDim.x * tile;
   for (int64_t base = (int64_t)blockIdx.x * tile; base < io.n; base += stride) {
     const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in, nullptr, nullptr, nullptr, 0, io.n - base};
@@ -466,9 +467,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
   {                                                                                                    \
     hit = test_surface<CFG>(S, r.p, r.d, f, t_raw);                                                    \
     if (__any(any_(hit))) {                                                                            \
-      T* st = state + (int64_t)s * kAdjState * kBlock;                                                 \
-      st[0] = r.p.x; st[kBlock] = r.p.y; st[2 * kBlock] = r.p.z;                                       \
-      st[3 * kBlock] = r.d.x; st[4 * kBlock] = r.d.y; st[5 * kBlock] = r.d.z; st[6 * kBlock] = t_raw;  \
+      T* st = state + (int64_t)s * kAdjState * BS;                                                 \
+      st[0] = r.p.x; st[BS] = r.p.y; st[2 * BS] = r.p.z;                                       \
+      st[3 * BS] = r.d.x; st[4 * BS] = r.d.y; st[5 * BS] = r.d.z; st[6 * BS] = t_raw;  \
       const Forward<T> fw = surface_forward<CFG>(S, r.p, r.d, f, t_raw);                               \
       V3<T> nd;                                                                                        \
       T im;                                                                                            \
@@ -510,13 +511,13 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
       const M hit = get_bits(bits, s);
       if (!__any(any_(hit))) continue;
       const RecF S{prog[s]};
-      const T* st = state + (int64_t)s * kAdjState * kBlock;
-      const V3<T> p = {st[0], st[kBlock], st[2 * kBlock]};
-      const V3<T> d = {st[3 * kBlock], st[4 * kBlock], st[5 * kBlock]};
-      const T t = st[6 * kBlock];
+      const T* st = state + (int64_t)s * kAdjState * BS;
+      const V3<T> p = {st[0], st[BS], st[2 * BS]};
+      const V3<T> d = {st[3 * BS], st[4 * BS], st[5 * BS]};
+      const T t = st[6 * BS];
       const M on = and_(hit, live);
       const bool all_on = __all(all_(on));
-      const SlotSink<T> sk = {acc, am.mask[s], (int)am.base[s], on, all_on};
+      const SlotSink<T> sk = {acc, BS, am.mask[s], (int)am.base[s], on, all_on};
       const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
       const int slot = S.r.sensor_slot;
       auto ext = [&](V3<T> hl) -> V3<T> {
@@ -564,11 +565,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
   // ---- block sums of the slot adjoints, float64 ----
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = wv; k < a.n_acc; k += kBlock / 64) {
-    const float* col = lds_dyn + (int64_t)k * kBlock;
+  for (int k = wv; k < a.n_acc; k += BS / 64) {
+    const float* col = lds_dyn + (int64_t)k * BS;
     double v = 0.0;
 #pragma unroll
-    for (int j = 0; j < kBlock / 64; ++j) v += (double)col[lane + 64 * j];
+    for (int j = 0; j < BS / 64; ++j) v += (double)col[lane + 64 * j];
     v = wave_sum(v);
     if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;  // read back by k_sum_partials with strides (n_acc, 1)
   }

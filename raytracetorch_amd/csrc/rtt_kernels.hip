@@ -2628,22 +2628,23 @@ constexpr int kAdjMaxBlocks = 2048;          // grid cap of the adjoint kernel =
 constexpr int kAdjMaxAcc = 128;              // accumulators per launch
 constexpr int kLdsBytes = 160 * 1024;        // LDS of a gfx950 compute unit
 int g_adjoint_lane = 0;                      // 0: choose by LDS need, 1: one ray per lane, 2: two rays per lane
+int g_adjoint_block = 256;                   // threads per block of the adjoint kernel (256 or 128)
 
-int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane) {
-  return (int64_t)kBlock * 4 * ((int64_t)n_acc + (int64_t)n_surf * kAdjState * rays_per_lane);
+int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, int block = kBlock) {
+  return (int64_t)block * 4 * ((int64_t)n_acc + (int64_t)n_surf * kAdjState * rays_per_lane);
 }
 
-template <class T>
+template <class T, int BS>
 int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
                    int vec, int64_t lds, int blocks, hipStream_t st) {
   static bool raised = false;  // dynamic LDS above 64 KB has to be granted once per kernel
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kLdsBytes) != hipSuccess)
       return RTT_E_LAUNCH;
     raised = true;
   }
-  hipLaunchKernelGGL((k_trace_seq_adjoint<T>), dim3(blocks), dim3(kBlock), (size_t)lds, st, io, prog_dev, n_surf, ops, am, a, vec);
+  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am, a, vec);
   return launch_status();
 }
 
@@ -2677,13 +2678,14 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   if (n_acc > 0 && (!slot_adj || !partials)) return RTT_E_NULL;
   int lanes = g_adjoint_lane;
   if (lanes == 0) lanes = adjoint_lds_bytes(n_surf, n_acc, 2) <= kLdsBytes / 2 ? 2 : 1;
-  const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes);
-  if (lds > kLdsBytes) return RTT_E_SIZE;
+  const int bs = g_adjoint_block;
+  if (adjoint_lds_bytes(n_surf, n_acc, lanes) > kLdsBytes) return RTT_E_SIZE;  // (the budget is stated for 256 threads)
+  const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes, bs);
   if (n == 0) {
     if (n_acc > 0 && hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) != hipSuccess) return RTT_E_LAUNCH;
     return RTT_OK;
   }
-  const int64_t tile = (int64_t)kBlock * lanes;
+  const int64_t tile = (int64_t)bs * lanes;
   int64_t blocks = (n + tile - 1) / tile;
   if (blocks > kAdjMaxBlocks) blocks = kAdjMaxBlocks;
   if (n_acc > 0 && blocks > partial_rows) return RTT_E_SIZE;
@@ -2694,8 +2696,12 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) && aligned8(adj_pos) &&
                   aligned8(adj_dir) && aligned8(adj_sens);
-  rc = lanes == 2 ? launch_adjoint<f2>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
-                  : launch_adjoint<float>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+  if (bs == 128)
+    rc = lanes == 2 ? launch_adjoint<f2, 128>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                    : launch_adjoint<float, 128>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+  else
+    rc = lanes == 2 ? launch_adjoint<f2, 256>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                    : launch_adjoint<float, 256>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
   if (rc != RTT_OK || n_acc == 0) return rc;
   hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, (int64_t)n_acc, (int64_t)1, slot_adj);
   return launch_status();
@@ -3075,6 +3081,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 6 && value >= 0 && value <= 2) {
     g_adjoint_lane = value;
+    return RTT_OK;
+  }
+  if (key == 7 && (value == 128 || value == 256)) {
+    g_adjoint_block = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;

@@ -12,6 +12,13 @@ from .rays.ray import Rays
 
 
 def _check_rays(rays: Rays):
+    p, d, w = rays._pos, rays._dir, rays.intensity
+    n = p.shape[1] if p.ndim == 2 else -1
+    f32 = torch.float32
+    if (p.dtype is f32 and d.dtype is f32 and w.dtype is f32 and p.is_cuda and d.is_cuda and w.is_cuda
+            and p.shape == (3, n) and d.shape == (3, n) and w.shape == (n,)
+            and p.is_contiguous() and d.is_contiguous() and w.is_contiguous()):
+        return n   # the usual case, decided without building messages
     N.require_device(rays._pos, rays._dir, rays.intensity)
     n = len(rays)
     for name, t, shape in (("pos", rays._pos, (3, n)), ("dir", rays._dir, (3, n)),
@@ -23,13 +30,24 @@ def _check_rays(rays: Rays):
     return n
 
 
-def _sensor_buffers(prog, n, device):
+def _call_on(dev, fn, *args):
+    """Call an entry point with `dev` as the current device (launches go to the current device); the switch is made
+    only when another device is current, the context manager costs as much as a small launch."""
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return fn(*args)
+    with torch.cuda.device(dev):
+        return fn(*args)
+
+
+def _sensor_buffers(prog, n, device, zero_mask=True):
+    """Dense sensor record of one launch.  The sequential trace writes the mask entry of every ray on every sensor
+    surface (`zero_mask=False`); a nearest-hit bounce only those of the rays that went to a sensor."""
     k = P.n_sensor_slots(prog)
     if k == 0:
         return None, None, None
     hit = torch.empty((k, 3, n), device=device, dtype=torch.float32)
     w = torch.empty((k, n), device=device, dtype=torch.float32)
-    mask = torch.zeros((k, n), device=device, dtype=torch.uint8)
+    mask = (torch.zeros if zero_mask else torch.empty)((k, n), device=device, dtype=torch.uint8)
     return hit, w, mask
 
 
@@ -44,7 +62,7 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=Non
     elif _check_rays(out) != n:
         raise ValueError("`out` must hold the same number of rays")
     dev = rays.device
-    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev)
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev, zero_mask=False)
     if n == 0 or prog.shape[0] == 0:
         if out is not rays:
             out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
@@ -67,13 +85,13 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=Non
                 N.stream_handle(dev))
         N.check(code, "rtt_trace_seq_moments_f32")
         return sens_hit, sens_w, sens_mask
-    with torch.cuda.device(dev):
-        code = N.lib().rtt_trace_seq_f32(
-            N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
-            N.ptr(out._pos), N.ptr(out._dir), N.ptr(out.intensity), n, n,
-            N.ptr(dp.dev), dp.host_ptr, dp.n,
-            N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, N.stream_handle(dev))
-    N.check(code, "rtt_trace_seq_f32")
+    code = _call_on(dev, N.lib().rtt_trace_seq_f32,
+                    rays._pos.data_ptr(), rays._dir.data_ptr(), rays.intensity.data_ptr(), n,
+                    out._pos.data_ptr(), out._dir.data_ptr(), out.intensity.data_ptr(), n, n,
+                    dp.dev.data_ptr(), dp.host_ptr, dp.n,
+                    N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, N.stream_handle(dev))
+    if code:
+        N.check(code, "rtt_trace_seq_f32")
     return sens_hit, sens_w, sens_mask
 
 

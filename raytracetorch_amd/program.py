@@ -124,6 +124,25 @@ def sag_f32(c, tz, r) -> np.float32:
     return f32((c * r_sq) / denom + tz)
 
 
+class Program(np.ndarray):
+    """The packed records of a scene, as `compile_elements` returns them: a structured array that also carries facts
+    derived from it once (`facts`: number of sensor slots, presence of a stochastic functor, device copies), so that a
+    repeated launch of an unchanged program does not derive them again.  Slices and copies are plain arrays of records
+    without facts."""
+
+    def __array_finalize__(self, obj):
+        self.facts = None
+
+
+def facts_of(prog):
+    """The dict of derived facts of a `Program` (created on first use), or None for a plain record array."""
+    if type(prog) is not Program:
+        return None
+    if prog.facts is None:
+        prog.facts = {}
+    return prog.facts
+
+
 def compile_elements(elements) -> np.ndarray:
     """Records for every (element, surface) in scene order (scene/base.py:113-123)."""
     recs = []
@@ -140,9 +159,25 @@ def compile_elements(elements) -> np.ndarray:
     if len(recs) > MAX_SURFACES:
         raise ValueError(f"scene has {len(recs)} surfaces; the kernels accept at most {MAX_SURFACES}")
     if not recs:
-        return np.zeros((0,), dtype=SURFACE_DTYPE)
-    return np.stack(recs)
+        return np.zeros((0,), dtype=SURFACE_DTYPE).view(Program)
+    return np.stack(recs).view(Program)
 
 
 def n_sensor_slots(prog) -> int:
-    return int(((prog["flags"] & F_SENSOR) != 0).sum())
+    facts = facts_of(prog)
+    if facts is None:
+        return int(((prog["flags"] & F_SENSOR) != 0).sum())
+    k = facts.get("sensor slots")
+    if k is None:
+        k = facts["sensor slots"] = int(((np.asarray(prog)["flags"] & F_SENSOR) != 0).sum())
+    return k
+
+
+def has_stochastic_functor(prog) -> bool:
+    facts = facts_of(prog)
+    if facts is None:
+        return bool((prog["phys_kind"] == PHYS_FRESNEL).any())
+    v = facts.get("stochastic")
+    if v is None:
+        v = facts["stochastic"] = bool((np.asarray(prog)["phys_kind"] == PHYS_FRESNEL).any())
+    return v

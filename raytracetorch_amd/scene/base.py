@@ -129,10 +129,10 @@ class Scene(nn.Module):
                 cached = (key, P.compile_elements(self.elements))
             self._prog_cache = cached
         prog = cached[1]
-        stochastic = prog["phys_kind"] == P.PHYS_FRESNEL
-        if stochastic.any():
+        if P.has_stochastic_functor(prog):
             # RefractFresnel draws new random numbers in every trace (phys/std.py:200): one key per call from
             # torch's default generator; the kernels add the surface's position to it
+            stochastic = prog["phys_kind"] == P.PHYS_FRESNEL
             key = int(torch.randint(0, 2 ** 62, (1,)).item())
             prog = prog.copy()
             prog["seed"][stochastic] = (key & 0xFFFFFFFF, key >> 32)

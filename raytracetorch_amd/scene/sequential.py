@@ -8,6 +8,7 @@ gather / scatter per surface visit.
 import torch.nn as nn
 
 from .. import kernels as K
+from ..rays.ray import Rays
 from .base import Scene
 
 
@@ -22,6 +23,12 @@ class SequentialScene(Scene):
         (scene/sequential.py:12-36).  With `out` (a second Rays of the same size) the result goes
         there and `rays` is left untouched."""
         prog = self._program()
+        if type(rays) is Rays and not self._needs_grad(rays):
+            # the common call: plain rays, nothing to differentiate
+            sens_hit, sens_w, sens_mask = K.trace_sequential(rays, prog, out=out)
+            if sens_hit is not None:
+                self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask, dst=out)
+            return rays if out is None else out
         from ..rays.ray import Paths
         if isinstance(rays, Paths):
             # visualisation path: in place on the wrapped rays, one snapshot per surface that was hit
