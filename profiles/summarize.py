@@ -26,7 +26,7 @@ for f in find("*counter_collection.csv"):
             agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print(f"\n## counters ({os.path.relpath(f, root)})  [mean per dispatch]")
     for k, cs in agg.items():
-        if not any(t in k for t in ("trace_seq", "simulate_nearest", "ray_cast", "spot_moments", "sample_bundle", "tangent")):
+        if not any(t in k for t in ("trace_seq", "simulate_nearest", "ray_cast", "spot_moments", "sample_bundle", "tangent", "adjoint", "sum_partials")):
             continue
         for c, v in cs.items():
             print(f"  {k[:50]:50s} {c:28s} n={len(v):3d} mean={sum(v) / len(v):.6g}")
