@@ -1095,7 +1095,11 @@ DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, I i, int nv) {
 // alignment of the batch it is traced in.
 // ------------------------------------------------------------------------------------------------
 // MOM: the first spot moments of sensor slot se.mom_slot are summed on the way (float per wavefront, float64 from
-// there on) and each block stores its three sums to mom_partials[k * gridDim.x + blockIdx.x].
+// there on) and each block adds its three sums to bin blockIdx.x % kMomBins of mom_partials[k * kMomBins + bin] (zeroed
+// by the launcher): a few dozen float64 atomics per address, spread over the launch, and a short second kernel adds
+// the bins.  (One row per block took the adding kernel 87 us for the 65536 blocks of a 32 Mi-ray launch.)
+constexpr int kMomBins = 1024;
+
 template <class T, int G, bool LDS_PROG, bool MOM = false>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                       Ops ops, SensorIO se, int vec, double* __restrict__ mom_partials = nullptr) {
@@ -1172,7 +1176,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
     if (threadIdx.x < 3) {
       double sum = 0.0;
       for (int w = 0; w < kBlock / 64; ++w) sum += mom_wave[threadIdx.x * (kBlock / 64) + w];
-      mom_partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
+      atomicAdd(&mom_partials[threadIdx.x * kMomBins + (blockIdx.x % kMomBins)], sum);
     }
   }
 }
@@ -2481,7 +2485,7 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
 }
 
 int64_t rtt_trace_seq_moments_workspace_bytes(int64_t n) {
-  return n < 0 ? 0 : (int64_t)sizeof(double) * 3 * grid_for(n, 2);
+  return n < 0 ? 0 : (int64_t)sizeof(double) * 3 * kMomBins;
 }
 
 int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
@@ -2505,7 +2509,8 @@ int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const fl
   const hipStream_t st = (hipStream_t)stream;
   if (n == 0) return hipMemsetAsync(mom, 0, 3 * sizeof(double), st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
   const int blocks = grid_for(n, 2);
-  if (workspace_bytes < (int64_t)sizeof(double) * 3 * blocks) return RTT_E_SIZE;
+  if (workspace_bytes < (int64_t)sizeof(double) * 3 * kMomBins) return RTT_E_SIZE;
+  if (hipMemsetAsync(workspace, 0, sizeof(double) * 3 * kMomBins, st) != hipSuccess) return RTT_E_LAUNCH;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
   se.mom_slot = mom_slot;
@@ -2516,7 +2521,8 @@ int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const fl
   hipLaunchKernelGGL((k_trace_seq<f2, 1, false, true>), dim3(blocks), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec,
                      (double*)workspace);
   if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
-  hipLaunchKernelGGL(k_sum_partials, dim3(3), dim3(kBlock), 0, st, (const double*)workspace, blocks, (int64_t)1, (int64_t)blocks, mom);
+  hipLaunchKernelGGL(k_sum_partials, dim3(3), dim3(kBlock), 0, st, (const double*)workspace, kMomBins, (int64_t)1, (int64_t)kMomBins,
+                     mom);
   return launch_status();
 }
 
