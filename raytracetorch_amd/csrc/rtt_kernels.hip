@@ -1911,6 +1911,23 @@ DI void spot_term(int pass, float xi, float yi, float wi, bool masked_in, double
 
 // VEC: four consecutive entries per lane and trip with 16-byte loads (the planes are 16-byte aligned), so that a
 // wavefront keeps 3 KB in flight instead of 0.8 KB: the pass is pure streaming and bound by the bytes in flight.
+// Passes 1 and 2 with the per-ray terms in float32, like the reference's tensors (hardware sqrt and reciprocal, one
+// multiplication by 1 / W instead of a division per ray); the caller adds the terms of a group of rays in float32
+// and the groups in float64.
+DI void spot_term_f(int pass, float xi, float yi, float wi, bool masked_in, float cx, float cy, float inv_w, float& g0,
+                    float& g1, float& g2) {
+  if (!(masked_in && wi > 0.0f)) return;
+  const float dx = xi - cx, dy = yi - cy;
+  const float wn = wi * inv_w;
+  const float u = sqrt_((dx * dx + dy * dy) * wn);
+  g0 += u;
+  if (pass == 2) {
+    const float inv = u > 0.0f ? wn * rcp_(u) : 0.0f;
+    g1 += dx * inv;
+    g2 += dy * inv;
+  }
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ w,
@@ -1930,6 +1947,7 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
     pass = 2;
   }
   const float wsum_f = (float)wsum;
+  const float cx_f = (float)cx, cy_f = (float)cy, inv_w = (float)(1.0 / wsum);
   constexpr int W = VEC ? 4 : 1;
   const int64_t stride = (int64_t)gridDim.x * kBlock * W;
   for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * W; i < n; i += stride) {
@@ -1938,6 +1956,17 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
       const float4 yv = *reinterpret_cast<const float4*>(y + i);
       const float4 wv = *reinterpret_cast<const float4*>(w + i);
       const uint32_t mv = mask ? *reinterpret_cast<const uint32_t*>(mask + i) : 0x01010101u;
+      if (pass != 0) {
+        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+        spot_term_f(pass, xv.x, yv.x, wv.x, (mv & 0xffu) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+        spot_term_f(pass, xv.y, yv.y, wv.y, (mv & 0xff00u) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+        spot_term_f(pass, xv.z, yv.z, wv.z, (mv & 0xff0000u) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+        spot_term_f(pass, xv.w, yv.w, wv.w, (mv & 0xff000000u) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+        a0 += (double)g0;
+        a1 += (double)g1;
+        a2 += (double)g2;
+        continue;
+      }
       spot_term(pass, xv.x, yv.x, wv.x, (mv & 0xffu) != 0, cx, cy, wsum_f, a0, a1, a2);
       spot_term(pass, xv.y, yv.y, wv.y, (mv & 0xff00u) != 0, cx, cy, wsum_f, a0, a1, a2);
       spot_term(pass, xv.z, yv.z, wv.z, (mv & 0xff0000u) != 0, cx, cy, wsum_f, a0, a1, a2);
