@@ -312,7 +312,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         if dist is not None:
             scene.grad_group = dist.group.WORLD
         surfaces = 4
-        kernel = ("k_trace_seq + k_spot_moments x2 + k_trace_seq_adjoint + k_sum_partials"
+        kernel = ("k_trace_seq<moments> + k_sum_partials + k_spot_moments + k_trace_seq_adjoint + k_sum_partials"
                   if os.environ.get("RTT_BACKWARD", "adjoint") == "adjoint" else
                   "k_trace_seq + k_spot_moments x2 + k_trace_seq_tangent<6, spot>")
 
@@ -451,19 +451,37 @@ def main():
         step = graph.replay
     for _ in range(a.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # Launch-bound sizes (a step of a few tens of microseconds): two event records per step would cost as much as the
+    # step, so one pair brackets all K steps and only the mean is reported.
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    per_step_events = (time.perf_counter() - t0) > 2e-4
+    pairs = a.steps if per_step_events else 1
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(pairs)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()
-        step()
-        e.record()
+    if per_step_events:
+        for s, e in ev:
+            s.record()
+            step()
+            e.record()
+    else:
+        ev[0][0].record()
+        for _ in range(a.steps):
+            step()
+        ev[0][1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dist, dev)
-    stats = timing_stats([s.elapsed_time(e) for s, e in ev])
+    if per_step_events:
+        stats = timing_stats([s.elapsed_time(e) for s, e in ev])
+    else:
+        stats = {"kernel_ms": ev[0][0].elapsed_time(ev[0][1]) / a.steps, "kernel_ms_min": None, "kernel_ms_median": None,
+                 "kernel_ms_max": None, "timing_note": "one HIP-event pair around all steps (launch-bound size)"}
     kernel_ms = stats["kernel_ms"]
     alive = int((out.intensity > 0).sum().item())
 
