@@ -381,7 +381,8 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * few addresses, which serialise at about 12 ns each, so more blocks cost more than they stream);
  * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048;
  * key 6: rays per lane of rtt_trace_seq_adjoint_f32: 0 (default) two when the LDS need allows two blocks per compute
- * unit, else one; 1 or 2 force the choice.
+ * unit, else one; 1 or 2 force the choice;
+ * key 7: threads per block of rtt_trace_seq_adjoint_f32, 256 (default) or 128.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 
