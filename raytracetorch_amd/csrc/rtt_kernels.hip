@@ -133,6 +133,10 @@ DI f2 quot_refined(f2 a, f2 b) {
   return __builtin_elementwise_fma(__builtin_elementwise_fma(-b, q, a), r, q);
 }
 template <class T> DI T splat(float v) { return T(v); }
+// float and packed float lanes (as opposed to dual numbers)
+template <class T> struct IsPlainLane { static constexpr bool value = false; };
+template <> struct IsPlainLane<float> { static constexpr bool value = true; };
+template <> struct IsPlainLane<f2> { static constexpr bool value = true; };
 DI float comp(float a, int) { return a; }
 DI float comp(f2 a, int k) { return k == 0 ? a.x : a.y; }
 DI bool set_mask(bool, int, bool v) { return v; }
@@ -843,13 +847,32 @@ DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im,
       return;
     }
     case RTT_PHYS_SNELL: {  // phys/std.py:123-145
-      const T dot = dot3(d, n);
+      T dot = dot3(d, n);
       const auto ent = lt(dot, zero);
-      const T c1 = abs_(dot);
+      T c1 = abs_(dot);
       const T mu = sel(ent, T(S.phys(2)), T(S.phys(3)));
-      const T term = 1.0f - mu * mu * (1.0f - c1 * c1);
+      T term = 1.0f - mu * mu * (1.0f - c1 * c1);
       // sqrt(relu(term)); a NaN term comes with a NaN c1, so the result is NaN through g either way
-      const T c2 = sqrt_(max_(term, zero));
+      T c2 = sqrt_(max_(term, zero));
+      if constexpr (IsPlainLane<T>::value) {
+        // Within a few degrees of the critical angle the root amplifies (d c2 = d term / 2 c2) the one or two ulp by
+        // which the hardware reciprocal and square root leave the normal off unit length.  For those rays the normal
+        // is brought to unit length to second order, n (3 - n.n) / 2, and the root is the refined one; for all
+        // others this costs a compare.  (The sign of d.n does not depend on the length of n.)
+        const auto near = lt(abs_(term), splat<T>(0.03f));
+        if (!kStrict && any_(near)) {
+          const T fix = 1.5f - 0.5f * dot3(n, n);
+          const V3<T> nu = scale(fix, n);
+          const T dot_u = dot3(d, nu);
+          const T c1_u = abs_(dot_u);
+          const T term_u = 1.0f - mu * mu * (1.0f - c1_u * c1_u);
+          n = sel3(near, nu, n);
+          dot = sel(near, dot_u, dot);
+          c1 = sel(near, c1_u, c1);
+          term = sel(near, term_u, term);
+          c2 = sel(near, sqrt_disc(max_(term_u, zero)), c2);
+        }
+      }
       // (mu c1 - c2) * (entering ? n : -n), the sign moved onto the scalar factor (exact)
       const T g = sel(ent, mu * c1 - c2, c2 - mu * c1);
       const V3<T> refr = scale(mu, d) + scale(g, n);
@@ -1395,7 +1418,7 @@ DI void offer(T t, int s, T& tmin, typename WinOf<T>::type& win) {
 }
 
 template <class T>
-DI T test_one(const RttSurface* __restrict__ prog, const Ops& ops, int s, V3<T> p, V3<T> d) {
+DI T test_one(const RttSurface* __restrict__ prog, int op, int s, V3<T> p, V3<T> d) {
   const RecF S{prog[s]};
   Frames<T> f;
   T t_raw = splat<T>(kInf), t = splat<T>(kInf);
@@ -1404,7 +1427,7 @@ DI T test_one(const RttSurface* __restrict__ prog, const Ops& ops, int s, V3<T> 
     const auto valid = test_surface<CFG>(S, p, d, f, t_raw);   \
     t = masked_t<CFG>(S, t_raw, valid);                        \
   }
-  RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+  RTT_DISPATCH(op, RTT_CALL)
 #undef RTT_CALL
   return t;
 }
@@ -1440,55 +1463,83 @@ DI typename LaneOf<T>::M sphere_beyond(const SphereTerms<T>& q, T tmin) {
 DI float first_comp(float v) { return v; }
 DI float first_comp(f2 v) { return v.x; }
 
+// The element table and the opcodes as the nearest-hit kernels hold them: lane e of every wavefront carries
+// element e (bounding sphere, first record, record count) and lane s the opcode of surface s, fetched once per
+// wavefront from the kernel arguments.  A wavefront-uniform entry is then a v_readlane away; reading it from the
+// argument segment instead costs a chain of dependent loads per element and per surface test.
+struct CullLanes {
+  int n;      // elements (0: no culling)
+  float R, cx, cy, cz;
+  int fc;     // first record | record count << 8
+  int op;     // lane s: opcode of surface s
+};
+DI CullLanes cull_lanes(const Cull& cull, const Ops& ops) {
+  static_assert(RTT_MAX_SURFACES <= 64 && kMaxCull <= 64, "one lane per surface and per element");
+  const int lane = threadIdx.x & 63;
+  const int e = lane & (kMaxCull - 1);
+  CullLanes L;
+  L.n = cull.n;
+  L.R = cull.R[e];
+  L.cx = cull.c[e][0];
+  L.cy = cull.c[e][1];
+  L.cz = cull.c[e][2];
+  L.fc = (int)cull.first[e] | ((int)cull.count[e] << 8);
+  L.op = op_of(ops, lane & (RTT_MAX_SURFACES - 1));
+  return L;
+}
+DI int lane_i(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+DI float lane_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+DI float first_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+DI float push_f(int to, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(to << 2, __float_as_int(v))); }
+
+// `use_act`: rays whose `act` is false take no part in the search and do not hold an element back.
 template <class T>
-DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const Ops& ops, V3<T> p, V3<T> d, T& tmin,
-                typename WinOf<T>::type& win, const Cull& cull, uint64_t skip = 0,
-                const typename LaneOf<T>::M* act = nullptr) {
+DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const CullLanes& L, V3<T> p, V3<T> d, T& tmin,
+                typename WinOf<T>::type& win, uint64_t skip, typename LaneOf<T>::M act, bool use_act) {
   tmin = splat<T>(kInf);
   win = typename WinOf<T>::type(0x7fffffff);
-  if (cull.n == 0) {
+  if (L.n == 0) {
     for (int s = 0; s < n_surf; ++s) {
       if ((skip >> s) & 1) continue;  // surfaces left out of the competition (wave-uniform)
-      offer(test_one<T>(prog, ops, s, p, d), s, tmin, win);
+      offer(test_one<T>(prog, lane_i(L.op, s), s, p, d), s, tmin, win);
     }
   } else {
     // Front-to-back over the elements, in the order the wavefront's first ray meets their bounding spheres
-    // (a heuristic: the rays of a wavefront are neighbours; a NaN key only changes the order).  An element is
-    // skipped when, for every ray of the wavefront, its sphere is missed or entered beyond the nearest hit found
-    // so far; since any t of the element is at least the entry distance, a skipped element can neither win nor tie.  Every lane of the wavefront is active
-    // here (the kernels clamp instead of masking), so lane e can hold the sort key of element e.
+    // (a heuristic: the rays of a wavefront are neighbours).  An element is skipped when, for every ray of the
+    // wavefront, its sphere is missed or entered beyond the nearest hit found so far; since any t of the element
+    // is at least the entry distance, a skipped element can neither win nor tie.  Every lane of the wavefront is
+    // active here (the kernels clamp instead of masking), so lane e can work on element e.
     const int lane = threadIdx.x & 63;
-    float key = 0.0f;
-    for (int e = 0; e < cull.n; ++e) {
-      float k = -kInf;
-      if (cull.R[e] >= 0.0f) {
-        const SphereTerms<T> q = sphere_terms(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
-        k = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(first_comp(q.b) - cull.R[e])));
-      }
-      key = lane == e ? k : key;
-    }
-    int rank = 0;  // lane e: number of elements visited before element e
-    for (int e = 0; e < cull.n; ++e) {
-      const float ke = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key), e));
+    const float px = first_f(first_comp(p.x)), py = first_f(first_comp(p.y)), pz = first_f(first_comp(p.z));
+    const float dx = first_f(first_comp(d.x)), dy = first_f(first_comp(d.y)), dz = first_f(first_comp(d.z));
+    // Sort key of element `lane`: b - R, a lower bound of the entry distance for a unit direction; elements without
+    // a bound come first.  The keys are compared as integers in an order that is total over every bit pattern
+    // (NaN included), so the ranks are a permutation whatever the ray holds, and every element is visited once.
+    const float kf = L.R >= 0.0f ? ((L.cx - px) * dx + (L.cy - py) * dy + (L.cz - pz) * dz) - L.R : -kInf;
+    const uint32_t kb = (uint32_t)__float_as_int(kf);
+    const int key = (int)((kb & 0x80000000u) ? ~kb : (kb | 0x80000000u)) ^ (int)0x80000000u;  // signed, monotone
+    int rank = 0;  // number of elements visited before element `lane`
+    for (int e = 0; e < L.n; ++e) {
+      const int ke = lane_i(key, e);
       rank += (ke < key || (ke == key && e < lane)) ? 1 : 0;
     }
-    uint64_t todo = cull.n >= 64 ? ~0ull : ((1ull << cull.n) - 1);  // elements not visited yet
-    for (int k = 0; k < cull.n; ++k) {
-      // the element of rank k; whatever the keys are, every element is visited exactly once
-      const uint64_t pick = __ballot(rank == k) & todo;
-      const int e = __builtin_ctzll(pick ? pick : todo);
-      todo &= ~(1ull << e);
-      if (cull.R[e] >= 0.0f) {
-        const SphereTerms<T> q = sphere_terms(p, d, cull.c[e][0], cull.c[e][1], cull.c[e][2], cull.R[e]);
-        // rays that take no part in this search (`act` false) do not hold an element back
+    rank = lane < L.n ? rank : lane;
+    // lane k receives the element of rank k
+    const float sR = push_f(rank, L.R), sx = push_f(rank, L.cx), sy = push_f(rank, L.cy), sz = push_f(rank, L.cz);
+    const int sfc = __builtin_amdgcn_ds_permute(rank << 2, L.fc);
+    for (int k = 0; k < L.n; ++k) {
+      const float R = lane_f(sR, k);
+      if (R >= 0.0f) {
+        const SphereTerms<T> q = sphere_terms(p, d, lane_f(sx, k), lane_f(sy, k), lane_f(sz, k), R);
         auto beyond = sphere_beyond(q, tmin);
-        if (act) beyond = or_(beyond, not_(*act));
+        if (use_act) beyond = or_(beyond, not_(act));
         if (__all(all_(beyond))) continue;
       }
-      const int s0 = cull.first[e], s1 = s0 + cull.count[e];
+      const int fc = lane_i(sfc, k);
+      const int s0 = fc & 0xff, s1 = s0 + (fc >> 8);
       for (int s = s0; s < s1; ++s) {
         if ((skip >> s) & 1) continue;
-        offer(test_one<T>(prog, ops, s, p, d), s, tmin, win);
+        offer(test_one<T>(prog, lane_i(L.op, s), s, p, d), s, tmin, win);
       }
     }
   }
@@ -1507,6 +1558,7 @@ __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ p
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
   const int64_t rounds = (n + stride - 1) / stride;
+  const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t r = 0; r < rounds; ++r) {
     const int64_t want = r * stride + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N;
     const bool live = want < n;
@@ -1517,7 +1569,7 @@ __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ p
     V3<T> d = {ld_(dir, i, vec != 0, nv, tag), ld_(dir + ld, i, vec != 0, nv, tag), ld_(dir + 2 * ld, i, vec != 0, nv, tag)};
     T tmin;
     typename WinOf<T>::type win;
-    nearest<T>(prog, n_surf, ops, p, d, tmin, win, cull);
+    nearest<T>(prog, n_surf, cl, p, d, tmin, win, 0, mask_all<typename LaneOf<T>::M>(true), false);
     if (!live) continue;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1533,24 +1585,30 @@ __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ p
 // the very operations of intersectTest, so both agree there by construction; re-solving here with a
 // differently contracted instruction stream could flip the `t <= 1e-6` filter for rays that start on a
 // surface (every bounce after the first) and turn a finite hit into an infinite one.
-DI void serve_winner(const RttSurface* __restrict__ prog, const Ops& ops, int win, float t, Ray<float>& r,
+DI void serve_winner(const RttSurface* __restrict__ prog, int opv, int win, float t, Ray<float>& r,
                      const SensorIO& se, int64_t i) {
   // active_mask = hit & (intensity > 0), scene/base.py:201
-  bool pending = (win >= 0) && (r.I > 0.0f);
-  // Lanes of one wavefront may have won different surfaces: serve one surface per pass with its
-  // record held in scalar registers (readfirstlane picks the surface of the first pending lane).
-  while (pending) {
-    const int s = __builtin_amdgcn_readfirstlane(win);
-    if (win == s) {
-      const RecF S{prog[s]};
+  const bool pending = (win >= 0) && (r.I > 0.0f);
+  // Lanes of one wavefront may have won different surfaces: one surface per pass, taken from the first lane
+  // that is still waiting, with its record in scalar registers.  The loop runs on ballots, so its trip count
+  // is wave-uniform; the surface index goes through an opaque copy, otherwise the compiler uses the equality
+  // `win == s` to address the record per lane (vector loads, one register set per field) and drops the loop.
+  uint64_t todo = __ballot(pending);
+  while (todo) {
+    const int s = __builtin_amdgcn_readlane(win, (int)__builtin_ctzll(todo));
+    const bool mine = pending && win == s;
+    todo &= ~__ballot(mine);
+    int su = s;
+    asm volatile("" : "+s"(su));
+    if (mine) {
+      const RecF S{prog[su]};
 #define RTT_CALL(CFG)                                  \
   {                                                    \
     Frames<float> f = to_frames<CFG>(S, r.p, r.d);     \
     interact<CFG>(S, f, t, true, r, se, i);            \
   }
-      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+      RTT_DISPATCH(lane_i(opv, su), RTT_CALL)
 #undef RTT_CALL
-      pending = false;
     }
   }
 }
@@ -1585,6 +1643,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
   const int64_t rounds = (io.n + stride - 1) / stride;
+  const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t rnd = 0; rnd < rounds; ++rnd) {
     const int64_t want = rnd * stride + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N;
     const bool live = want < io.n;
@@ -1614,7 +1673,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
       typename WinOf<T>::type win;
       // when the cast result is wanted for every ray (also those without intensity), no ray is left out of
       // the culling decisions
-      nearest<T>(prog, n_surf, ops, r.p, r.d, tmin, win, cull, 0, (winner && b == 0) ? nullptr : &act);
+      nearest<T>(prog, n_surf, cl, r.p, r.d, tmin, win, 0, act, !(winner && b == 0));
       seb.bounce = b;
       if (winner && b == 0 && live) {  // Scene.ray_cast result of the first bounce, for every ray
 #pragma unroll
@@ -1632,7 +1691,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
           continue;
         }
         Ray<float> rk = ray_comp(r, k);
-        serve_winner(prog, ops, wk, comp(tmin, k), rk, seb, i + k);
+        serve_winner(prog, cl.op, wk, comp(tmin, k), rk, seb, i + k);
         ray_set(r, k, rk);
         ++taken[k];
       }
@@ -1668,6 +1727,7 @@ __global__ void __launch_bounds__(kBlock) k_simulate_nearest_tangent(RayIO io, c
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const int64_t rounds = (io.n + stride - 1) / stride;
+  const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t rnd = 0; rnd < rounds; ++rnd) {
     const int64_t want = rnd * stride + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = want < io.n;
@@ -1687,8 +1747,8 @@ __global__ void __launch_bounds__(kBlock) k_simulate_nearest_tangent(RayIO io, c
       if (!__any(act)) break;
       float tmin;
       int win;
-      nearest<float>(prog, n_surf, ops, V3<float>{r.p.x.v, r.p.y.v, r.p.z.v}, V3<float>{r.d.x.v, r.d.y.v, r.d.z.v}, tmin, win, cull,
-                     0, &act);
+      nearest<float>(prog, n_surf, cl, V3<float>{r.p.x.v, r.p.y.v, r.p.z.v}, V3<float>{r.d.x.v, r.d.y.v, r.d.z.v}, tmin, win,
+                     0, act, true);
       if (act && win < 0) open = false;
       bool pending = act && win >= 0;
       while (pending) {  // one surface per pass, its record and tangent rows addressed from scalar registers
@@ -1763,6 +1823,7 @@ __global__ void __launch_bounds__(kBlock) k_render(const float* __restrict__ pos
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const int64_t rounds = (n + stride - 1) / stride;
+  const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t rnd = 0; rnd < rounds; ++rnd) {
     const int64_t want = rnd * stride + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = want < n;
@@ -1771,7 +1832,7 @@ __global__ void __launch_bounds__(kBlock) k_render(const float* __restrict__ pos
     const V3<float> d = {dir[i], dir[ld + i], dir[2 * ld + i]};
     float tmin;
     int win;
-    nearest<float>(prog, n_surf, ops, p, d, tmin, win, cull, sh.skip);
+    nearest<float>(prog, n_surf, cl, p, d, tmin, win, sh.skip, true, false);
     if (!live) continue;
     V3<float> c = {sh.bg[0], sh.bg[1], sh.bg[2]};
     bool pending = win >= 0;
