@@ -112,12 +112,18 @@ def test_naive32_full_size(ns):
     for el in scenes.naive32(ns):
         scene.add_element(el)
     prog = P.compile_elements(scene.elements)
-    rays = device_disk_rays(ns, n, seed=13, radius=6.5, z=-10.0, tilt=0.03)
-    # second half of the bundle starts between the lenses pointing backwards / sideways
+    # first half: the benchmark's collimated bundle, kept inside the clear aperture of the first lens (radius 6): a
+    # collimated ray that grazes the lens edge has a distance no float32 evaluation agrees on to 1e-5, the reference's
+    # own float32 is 1.4e-5 off its float64 there
+    rays = device_disk_rays(ns, n, seed=13, radius=5.9, z=-10.0, tilt=0.03)
+    # second half, the stress bundle: a quarter is the same collimated bundle widened beyond the lens (rays that graze
+    # the edges or fly past to later elements), a quarter starts between the lenses pointing anywhere
     h = n // 2
-    rays._pos[2, h:] = 44.5
+    q = h + n // 4
+    rays._pos[:, h:q] = device_disk_rays(ns, q - h, seed=14, radius=6.5, z=-10.0, tilt=0.03)._pos
+    rays._pos[2, q:] = 44.5
     gen = torch.Generator(device=DEV); gen.manual_seed(29)
-    rays._dir[:, h:] = torch.nn.functional.normalize(torch.randn(3, n - h, device=DEV, generator=gen), dim=0)
+    rays._dir[:, q:] = torch.nn.functional.normalize(torch.randn(3, n - q, device=DEV, generator=gen), dim=0)
     before = rays.clone()
     hit, el_ids, sf_ids = scene.ray_cast(rays)
     idx = torch.arange(0, n, n // 32768, device=DEV)[:32768]

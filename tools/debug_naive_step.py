@@ -37,7 +37,7 @@ gen = torch.Generator(device=DEV); gen.manual_seed(int(os.environ.get('SEED', '5
 rays._dir[:, h:] = torch.nn.functional.normalize(torch.randn(3, n - h, device=DEV, generator=gen), dim=0)
 before = rays.clone()
 m = int(os.environ.get('SAMPLES', '131072'))
-idx = torch.arange(h, n, (n - h) // m, device=DEV)[:m]
+idx = (torch.arange(0, h, h // m, device=DEV)[:m] if os.environ.get('HALF') == 'base' else torch.arange(h, n, (n - h) // m, device=DEV)[:m])
 p, d, I = before.pos[idx].cpu().numpy(), before.dir[idx].cpu().numpy(), before.intensity[idx].cpu().numpy()
 scene.rays = rays
 scene.step()
