@@ -1580,49 +1580,51 @@ __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ p
   }
 }
 
-// one ray of a lane through the surface it won (Element.forward + scatter_update, scene/base.py:213-235)
+// The rays of a lane through the surfaces they won (Element.forward + scatter_update, scene/base.py:213-235).
 // `t` is the winner's distance from the cast itself: the reference recomputes it in Element.forward with
 // the very operations of intersectTest, so both agree there by construction; re-solving here with a
 // differently contracted instruction stream could flip the `t <= 1e-6` filter for rays that start on a
 // surface (every bounce after the first) and turn a finite hit into an infinite one.
-DI void serve_winner(const RttSurface* __restrict__ prog, int opv, int win, float t, Ray<float>& r,
-                     const SensorIO& se, int64_t i) {
-  // active_mask = hit & (intensity > 0), scene/base.py:201
-  const bool pending = (win >= 0) && (r.I > 0.0f);
-  // Lanes of one wavefront may have won different surfaces: one surface per pass, taken from the first lane
-  // that is still waiting, with its record in scalar registers.  The loop runs on ballots, so its trip count
-  // is wave-uniform; the surface index goes through an opaque copy, otherwise the compiler uses the equality
-  // `win == s` to address the record per lane (vector loads, one register set per field) and drops the loop.
-  uint64_t todo = __ballot(pending);
-  while (todo) {
-    const int s = __builtin_amdgcn_readlane(win, (int)__builtin_ctzll(todo));
-    const bool mine = pending && win == s;
-    todo &= ~__ballot(mine);
+// `pend`: the rays that have a winner and carry intensity (active_mask = hit & (intensity > 0), scene/base.py:201).
+// Rays of one wavefront may have won different surfaces: one surface per pass, taken from the first ray that is
+// still waiting, with its record in scalar registers and the lane's rays on packed registers (adjacent rays mostly
+// win the same surface, so both components of a lane are usually served by the same pass).  The loop runs on
+// ballots, so its trip count is wave-uniform; the surface index goes through an opaque copy, otherwise the
+// compiler uses the equality `win == s` to address the record per lane (vector loads, one register set per field)
+// and drops the loop.
+template <class T>
+DI void serve_winners(const RttSurface* __restrict__ prog, int opv, typename WinOf<T>::type win, T t,
+                      typename LaneOf<T>::M pend, Ray<T>& r, const SensorIO& se, int64_t i, int nv) {
+  constexpr int N = LaneOf<T>::N;
+  using M = typename LaneOf<T>::M;
+  uint64_t todo[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) todo[k] = __ballot(mcomp(pend, k));
+  for (;;) {
+    int s = -1;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k)
+      if (todo[k]) s = __builtin_amdgcn_readlane(icomp(win, k), (int)__builtin_ctzll(todo[k]));
+    if (s < 0) break;
+    M mine = mask_all<M>(false);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const bool m = mcomp(pend, k) && icomp(win, k) == s;
+      mine = set_mask(mine, k, m);
+      todo[k] &= ~__ballot(m);
+    }
     int su = s;
     asm volatile("" : "+s"(su));
-    if (mine) {
+    if (any_(mine)) {
       const RecF S{prog[su]};
 #define RTT_CALL(CFG)                                  \
   {                                                    \
-    Frames<float> f = to_frames<CFG>(S, r.p, r.d);     \
-    interact<CFG>(S, f, t, true, r, se, i);            \
+    Frames<T> f = to_frames<CFG>(S, r.p, r.d);         \
+    interact<CFG>(S, f, t, mine, r, se, i, nv);        \
   }
       RTT_DISPATCH(lane_i(opv, su), RTT_CALL)
 #undef RTT_CALL
     }
-  }
-}
-
-DI Ray<float> ray_comp(const Ray<float>& r, int) { return r; }
-DI Ray<float> ray_comp(const Ray<f2>& r, int k) {
-  return {{comp(r.p.x, k), comp(r.p.y, k), comp(r.p.z, k)}, {comp(r.d.x, k), comp(r.d.y, k), comp(r.d.z, k)}, comp(r.I, k)};
-}
-DI void ray_set(Ray<float>& r, int, const Ray<float>& v) { r = v; }
-DI void ray_set(Ray<f2>& r, int k, const Ray<float>& v) {
-  if (k == 0) {
-    r.p.x.x = v.p.x; r.p.y.x = v.p.y; r.p.z.x = v.p.z; r.d.x.x = v.d.x; r.d.y.x = v.d.y; r.d.z.x = v.d.z; r.I.x = v.I;
-  } else {
-    r.p.x.y = v.p.x; r.p.y.y = v.p.y; r.p.z.y = v.p.z; r.d.x.y = v.d.x; r.d.y.y = v.d.y; r.d.z.y = v.d.z; r.I.y = v.I;
   }
 }
 
@@ -1680,21 +1682,16 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         for (int k = 0; k < N; ++k)
           if (k < nv) winner[i + k] = icomp(win, k);
       }
-      // one copy of the winner dispatch serves both packed components in turn (the dispatch is the bulk of the
-      // kernel's code and registers)
-#pragma unroll 1
+      M pend = mask_all<M>(false);
+#pragma unroll
       for (int k = 0; k < N; ++k) {
-        if (!mcomp(act, k)) continue;
-        const int wk = icomp(win, k);
-        if (wk < 0) {
-          open[k] = false;
-          continue;
-        }
-        Ray<float> rk = ray_comp(r, k);
-        serve_winner(prog, cl.op, wk, comp(tmin, k), rk, seb, i + k);
-        ray_set(r, k, rk);
-        ++taken[k];
+        const bool a = mcomp(act, k);
+        const bool won = icomp(win, k) >= 0;
+        if (a && !won) open[k] = false;
+        pend = set_mask(pend, k, a && won);
+        taken[k] += (a && won) ? 1 : 0;
       }
+      serve_winners<T>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
     }
     if (!live) continue;
     store_ray<T>(io, i, r, vec != 0, nv);
