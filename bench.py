@@ -177,6 +177,25 @@ def measured_traffic(workload, n):
     return None, reason
 
 
+def measured_issue(workload, n):
+    """Issue-side counters of the step's longest kernel from the same committed profile (same validity rule as the
+    traffic): share of the kernel's cycles in which the vector / scalar unit of a SIMD issues, and vector instructions
+    per ray.  For the kernels that are bound by instruction issue and latency rather than by HBM this, not the HBM
+    fraction, says how close they run to their bound.  None when there is no profile of the loaded build."""
+    import glob
+    sha = lib_sha16()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"traffic_{workload}.json")), reverse=True):
+        d = json.load(open(f))
+        if d.get("rays_per_gpu") != n or d.get("lib_sha16") != sha or not d.get("kernels"):
+            continue
+        name, k = max(d["kernels"].items(), key=lambda kv: kv[1].get("avg_us", 0.0) * kv[1].get("launches_per_step", 1.0))
+        if "valu_busy" not in k:
+            return None
+        return {"kernel": name[:48], "kernel_us": k.get("avg_us"), "valu_busy": k.get("valu_busy"), "salu_busy": k.get("salu_busy"),
+                "valu_insts_per_ray": k.get("valu_insts_per_ray"), "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def timing_stats(ms):
     return {"kernel_ms": statistics.mean(ms), "kernel_ms_min": min(ms), "kernel_ms_median": statistics.median(ms),
             "kernel_ms_max": max(ms)}
@@ -247,6 +266,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
                                           torch.zeros(n, device=dev))
     rays = mk(pos, d)
     kernel = "k_trace_seq"
+    pre = None   # untimed preparation of a step, where the step consumes its input
     if a.workload == "system5":
         elements = scenes.system5(ns)
         scene = ns.SequentialScene(elements)
@@ -299,10 +319,12 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         surfaces = 32
         kernel = "k_simulate_nearest (one bounce)"
 
-        def step():
+        def pre():   # (the bounce works in place: start every step from the same rays; not part of the bounce)
             work._pos.copy_(rays._pos); work._dir.copy_(rays._dir); work.intensity.copy_(rays.intensity)
             scene.elements[-1].reset()
             scene.rays = work
+
+        def step():
             scene.step()
         bytes_per_ray = 56 + 1
     else:
@@ -332,15 +354,23 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         if dist is not None:
             dist.barrier()
 
+    prepare = pre
     for _ in range(a.warmup):
+        if prepare:
+            prepare()
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    idle = 0.0
     for s, e in ev:
+        if prepare:   # untimed: the wall clock is stopped while the input of the next step is restored
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            prepare()
+            torch.cuda.synchronize(); idle += time.perf_counter() - t1
         s.record(); step(); e.record()
     torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0 - idle
     elapsed = max_over_ranks(elapsed, dist, dev)
     stats = timing_stats([s.elapsed_time(e) for s, e in ev])
     gpu_ms = stats["kernel_ms"]
@@ -362,6 +392,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": kernel, **stats,
                          "algorithmic_bytes_per_launch": bytes_per_ray * n,
+                         "issue": measured_issue(a.workload, n),
                          "note": "event time spans every kernel of the step, including torch glue"}}
         base = None if (world > 1 or a.no_cpu_baseline) else cpu_baseline_other(a.workload, scenes, ns)
         if base is not None:
@@ -504,7 +535,8 @@ def main():
             "rays_per_s": world * n / (elapsed / a.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "k_trace_seq", **stats, "algorithmic_bytes_per_launch": BYTES_PER_RAY * n},
+                         "kernel": "k_trace_seq", **stats, "algorithmic_bytes_per_launch": BYTES_PER_RAY * n,
+                         "issue": measured_issue("singlet", n)},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_rays, scenes, ns)

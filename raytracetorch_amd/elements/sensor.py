@@ -46,6 +46,15 @@ class Sensor(Element):
         if d["_dense_bytes"] > self._DENSE_LIMIT and len(self._dense) > 1:
             self._flush()
 
+    def _record_visit(self, visit):
+        """A visit whose tensors are still views to be made (`kernels.SensorVisit`, a 4-sequence like the tuples
+        above)."""
+        d = self.__dict__
+        d["_dense"].append(visit)
+        d["_dense_bytes"] += 17 * visit.n
+        if d["_dense_bytes"] > self._DENSE_LIMIT and len(d["_dense"]) > 1:
+            self._flush()
+
     def _record_hits(self, locs, w, ids):
         """One list entry of already compacted hits (rows in ray order)."""
         self._flush()

@@ -3,6 +3,8 @@
 Each function validates devices / shapes / dtypes on the host, allocates outputs with torch (the
 C side never allocates) and enqueues one kernel on the current torch stream of the rays' device.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -11,8 +13,22 @@ from . import program as P
 from .rays.ray import Rays
 
 
+_checked = [(None, None, None, -1), (None, None, None, -1)]   # the last two plane triples that passed (weak refs) + ray count
+
+
 def _check_rays(rays: Rays):
     p, d, w = rays._pos, rays._dir, rays.intensity
+    for c in _checked:
+        # the very tensors of an earlier call (a stepping loop, an optimisation loop, an in/out pair): already checked
+        if c[0] is not None and c[0]() is p and c[1]() is d and c[2]() is w and p.shape[1] == c[3]:
+            return c[3]
+    n = _check_rays_full(rays, p, d, w)
+    _checked[1] = _checked[0]
+    _checked[0] = (weakref.ref(p), weakref.ref(d), weakref.ref(w), n)
+    return n
+
+
+def _check_rays_full(rays, p, d, w):
     n = p.shape[1] if p.ndim == 2 else -1
     f32 = torch.float32
     if (p.dtype is f32 and d.dtype is f32 and w.dtype is f32 and p.is_cuda and d.is_cuda and w.is_cuda
@@ -49,6 +65,90 @@ def _sensor_buffers(prog, n, device, zero_mask=True):
     w = torch.empty((k, n), device=device, dtype=torch.float32)
     mask = (torch.zeros if zero_mask else torch.empty)((k, n), device=device, dtype=torch.uint8)
     return hit, w, mask
+
+
+class SensorRecord:
+    """Dense sensor record of one launch in ONE allocation: hit planes [K,3,N] float32, incoming intensities [K,N]
+    float32 and hit masks [K,N] uint8 behind one another.  The launch only needs the three addresses; the tensor
+    views are made when somebody reads them (a view costs as much as an allocation, and a small trace is all host
+    time)."""
+    __slots__ = ("buf", "k", "n", "_views")
+
+    def __init__(self, k, n, device):
+        self.k, self.n = k, n
+        self.buf = torch.empty((4 * k * n + (k * n + 3) // 4,), device=device, dtype=torch.float32)
+        self._views = None
+
+    def pointers(self):
+        base = self.buf.data_ptr()
+        return base, base + 12 * self.k * self.n, base + 16 * self.k * self.n
+
+    def views(self):
+        """(hit [K,3,N], w [K,N], mask [K,N] uint8)"""
+        v = self._views
+        if v is None:
+            k, n, f = self.k, self.n, self.buf
+            v = self._views = (f[:3 * k * n].view(k, 3, n), f[3 * k * n:4 * k * n].view(k, n),
+                               f[4 * k * n:].view(torch.uint8)[:k * n].view(k, n))
+        return v
+
+
+class SensorVisit:
+    """What one sensor slot recorded in one launch, as the 4-sequence (hit planes [3,N], w [N], mask [N], ids [N]) the
+    sensors keep per visit; the views into the launch's record are made on first use."""
+    __slots__ = ("record", "slot", "ids", "_items")
+
+    def __init__(self, record, slot, ids):
+        self.record, self.slot, self.ids, self._items = record, slot, ids, None
+
+    def _resolve(self):
+        it = self._items
+        if it is None:
+            hit, w, mask = self.record.views()
+            it = self._items = (hit[self.slot], w[self.slot], mask[self.slot], self.ids)
+        return it
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __getitem__(self, i):
+        return self._resolve()[i]
+
+    def __len__(self):
+        return 4
+
+    @property
+    def n(self):
+        return self.record.n
+
+
+def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
+    """trace_sequential for the plain call (no moments): returns the launch's SensorRecord, or None for a program
+    without sensor slots."""
+    n = _check_rays(rays)
+    if out is None:
+        out = rays
+    elif _check_rays(out) != n:
+        raise ValueError("`out` must hold the same number of rays")
+    k = P.n_sensor_slots(prog)
+    if n == 0 or prog.shape[0] == 0:
+        if out is not rays:
+            out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
+        return SensorRecord(k, n, rays.device) if k else None
+    dev = rays.device
+    dp = N.DeviceProgram.upload(prog, dev)
+    if k:
+        rec = SensorRecord(k, n, dev)
+        hit_p, w_p, mask_p = rec.pointers()
+    else:
+        rec, hit_p, w_p, mask_p = None, None, None, None
+    code = _call_on(dev, N.lib().rtt_trace_seq_f32,
+                    rays._pos.data_ptr(), rays._dir.data_ptr(), rays.intensity.data_ptr(), n,
+                    out._pos.data_ptr(), out._dir.data_ptr(), out.intensity.data_ptr(), n, n,
+                    dp.dev.data_ptr(), dp.host_ptr, dp.n, hit_p, w_p, mask_p, n, N.stream_handle(dev))
+    if code:
+        N.check(code, "rtt_trace_seq_f32")
+    return rec
 
 
 def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=None):

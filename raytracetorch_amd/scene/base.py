@@ -89,7 +89,7 @@ class Scene(nn.Module):
     def _element_params(self):
         """(ids of the elements, parameters of the scene), re-collected only when the element list changes:
         walking the module tree costs more than launching a small trace."""
-        els = tuple(id(el) for el in self.elements)
+        els = tuple(map(id, self.elements._modules.values()))
         plist = self.__dict__.get("_param_list")
         if plist is None or plist[0] != els:
             # the entry keeps the elements themselves: while it exists none of them can be freed and hand its id to a
@@ -120,7 +120,7 @@ class Scene(nn.Module):
             views = self.__dict__["_param_views"] = (
                 (els, ptrs), [q.detach().reshape(-1).numpy() for q in params if q.device.type == "cpu"],
                 [q for q in params if q.device.type != "cpu"])
-        values = np.concatenate(views[1]).tobytes() if views[1] else b""
+        values = b"".join([v.tobytes() for v in views[1]])
         key = (els, ptrs, values, tuple(map(_VERSION, views[2])))
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
@@ -149,9 +149,13 @@ class Scene(nn.Module):
     def _slot_plan(self, prog):
         """[(sensor slot, element, intensity function of a Fuzzy filter or None)] in program order, kept while the
         element list is the same (the per-record walk costs as much as a small launch)."""
-        key = (self._element_params()[0], prog.shape[0])   # slots depend on the element list, not on parameter values
         plan = self.__dict__.get("_slot_plan_cache")
-        if plan is None or plan[0] != key:
+        if plan is not None and plan[2] is prog:   # the cached program object itself: nothing to compare
+            return plan[1]
+        key = (self._element_params()[0], prog.shape[0])   # slots depend on the element list, not on parameter values
+        if plan is not None and plan[0] == key:
+            plan = self.__dict__["_slot_plan_cache"] = (key, plan[1], prog)
+        else:
             rows = []
             for rec in prog:
                 k = int(rec["sensor_slot"])
@@ -159,8 +163,19 @@ class Scene(nn.Module):
                     el = self.elements[int(rec["element_id"])]
                     fn = el.surface_functions[int(rec["surface_id"])]
                     rows.append((k, el, getattr(fn, "block_function", None)))
-            plan = self.__dict__["_slot_plan_cache"] = (key, rows)
+            plan = self.__dict__["_slot_plan_cache"] = (key, rows, prog)
         return plan[1]
+
+    def _deliver_sensor_visits(self, prog, rays, record, dst=None):
+        """The same for a launch whose record is still one allocation (`kernels.SensorRecord`): every sensor gets a
+        `SensorVisit` that makes its views when it is read.  A Fuzzy filter needs the tensors at once."""
+        plan = self._slot_plan(prog)
+        for row in plan:
+            if row[2] is not None:
+                return self._deliver_sensor_records(prog, rays, *record.views(), dst=dst)
+        ids = rays.id
+        for k, el, _ in plan:
+            el._record_visit(K.SensorVisit(record, k, ids))
 
     def _deliver_sensor_records(self, prog, rays, sens_hit, sens_w, sens_mask, dst=None):
         """Hand the dense records of a trace to the sensors.  Slots are numbered in program order; a Fuzzy

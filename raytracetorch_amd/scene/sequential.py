@@ -25,9 +25,9 @@ class SequentialScene(Scene):
         prog = self._program()
         if type(rays) is Rays and not self._needs_grad(rays):
             # the common call: plain rays, nothing to differentiate
-            sens_hit, sens_w, sens_mask = K.trace_sequential(rays, prog, out=out)
-            if sens_hit is not None:
-                self._deliver_sensor_records(prog, rays, sens_hit, sens_w, sens_mask, dst=out)
+            rec = K.trace_sequential_record(rays, prog, out=out)
+            if rec is not None:
+                self._deliver_sensor_visits(prog, rays, rec, dst=out)
             return rays if out is None else out
         from ..rays.ray import Paths
         if isinstance(rays, Paths):
