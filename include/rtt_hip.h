@@ -377,12 +377,13 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * key 2: 1 stages the surface program in LDS, 0 (default) reads it with scalar loads;
  * key 3: 0 makes the nearest-hit kernels test every surface for every ray, 1 (default) lets them skip elements
  * whose bounding sphere lies beyond the nearest hit found so far (same results);
- * key 4: number of blocks of rtt_spot_moments_f32 (default 768: every block ends in float64 atomics on the same
+ * key 4: number of blocks of rtt_spot_moments_f32 (default 512: every block ends in float64 atomics on the same
  * few addresses, which serialise at about 12 ns each, so more blocks cost more than they stream);
  * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048;
  * key 6: rays per lane of rtt_trace_seq_adjoint_f32: 0 (default) two when the LDS need allows two blocks per compute
  * unit, else one; 1 or 2 force the choice;
- * key 7: threads per block of rtt_trace_seq_adjoint_f32, 256 (default) or 128.
+ * key 7: threads per block of rtt_trace_seq_adjoint_f32, 256 (default) or 128;
+ * key 8: threads per block of rtt_spot_moments_f32 on 16-byte aligned records, 1024 (default) or 256.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

@@ -1986,13 +1986,13 @@ DI void spot_term_f(int pass, float xi, float yi, float wi, bool masked_in, floa
   }
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict__ x, const float* __restrict__ y,
+template <bool VEC, int BS = kBlock>
+__global__ void __launch_bounds__(BS) k_spot_moments(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ w,
                                                          const uint8_t* __restrict__ mask, int64_t n, int pass,
                                                          double cx, double cy, double wsum,
                                                          double* __restrict__ out) {
-  __shared__ double part[3][kBlock / 64];
+  __shared__ double part[3][BS / 64];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   if (pass >= 3) {
     // passes 3 and 4 are pass 2 with the weight sum taken from out[0] (clamped like the reference's W) and, in pass 3,
@@ -2007,8 +2007,32 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
   const float wsum_f = (float)wsum;
   const float cx_f = (float)cx, cy_f = (float)cy, inv_w = (float)(1.0 / wsum);
   constexpr int W = VEC ? 4 : 1;
-  const int64_t stride = (int64_t)gridDim.x * kBlock * W;
-  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * W; i < n; i += stride) {
+  const int64_t stride = (int64_t)gridDim.x * BS * W;
+  int64_t i = ((int64_t)blockIdx.x * BS + threadIdx.x) * W;
+  if (VEC && pass != 0) {
+    // two trips at once: both groups of loads are issued before the first is used (6 KB in flight per wavefront)
+    for (; i + stride + 4 <= n; i += 2 * stride) {
+      const int64_t j = i + stride;
+      const float4 xa = *reinterpret_cast<const float4*>(x + i), xb = *reinterpret_cast<const float4*>(x + j);
+      const float4 ya = *reinterpret_cast<const float4*>(y + i), yb = *reinterpret_cast<const float4*>(y + j);
+      const float4 wa = *reinterpret_cast<const float4*>(w + i), wb = *reinterpret_cast<const float4*>(w + j);
+      const uint32_t ma = mask ? *reinterpret_cast<const uint32_t*>(mask + i) : 0x01010101u;
+      const uint32_t mb = mask ? *reinterpret_cast<const uint32_t*>(mask + j) : 0x01010101u;
+      float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, h0 = 0.0f, h1 = 0.0f, h2 = 0.0f;
+      spot_term_f(pass, xa.x, ya.x, wa.x, (ma & 0xffu) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+      spot_term_f(pass, xa.y, ya.y, wa.y, (ma & 0xff00u) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+      spot_term_f(pass, xa.z, ya.z, wa.z, (ma & 0xff0000u) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+      spot_term_f(pass, xa.w, ya.w, wa.w, (ma & 0xff000000u) != 0, cx_f, cy_f, inv_w, g0, g1, g2);
+      spot_term_f(pass, xb.x, yb.x, wb.x, (mb & 0xffu) != 0, cx_f, cy_f, inv_w, h0, h1, h2);
+      spot_term_f(pass, xb.y, yb.y, wb.y, (mb & 0xff00u) != 0, cx_f, cy_f, inv_w, h0, h1, h2);
+      spot_term_f(pass, xb.z, yb.z, wb.z, (mb & 0xff0000u) != 0, cx_f, cy_f, inv_w, h0, h1, h2);
+      spot_term_f(pass, xb.w, yb.w, wb.w, (mb & 0xff000000u) != 0, cx_f, cy_f, inv_w, h0, h1, h2);
+      a0 += (double)g0 + (double)h0;
+      a1 += (double)g1 + (double)h1;
+      a2 += (double)g2 + (double)h2;
+    }
+  }
+  for (; i < n; i += stride) {
     if (VEC && i + 4 <= n) {
       const float4 xv = *reinterpret_cast<const float4*>(x + i);
       const float4 yv = *reinterpret_cast<const float4*>(y + i);
@@ -2046,7 +2070,7 @@ __global__ void __launch_bounds__(kBlock) k_spot_moments(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < kBlock / 64; ++k) {
+    for (int k = 0; k < BS / 64; ++k) {
       s0 += part[0][k];
       s1 += part[1][k];
       s2 += part[2][k];
@@ -2958,9 +2982,10 @@ int rtt_apply_physics_f32(const float* hit_local, const float* dir, const float*
   return launch_status();
 }
 
-static int g_moments_blocks = 768;
-static int moments_grid(int64_t n) {
-  int64_t blocks = (n + kBlock - 1) / kBlock;
+static int g_moments_blocks = 512;
+static int g_moments_threads = 1024;
+static int moments_grid(int64_t n, int threads = kBlock) {
+  int64_t blocks = (n + threads - 1) / threads;
   if (blocks > g_moments_blocks) blocks = g_moments_blocks;
   return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -2973,8 +2998,12 @@ int rtt_spot_moments_f32(const float* x, const float* y, const float* w, const u
   if (n == 0) return RTT_OK;
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   if (aligned16(x) && aligned16(y) && aligned16(w) && (reinterpret_cast<uintptr_t>(mask) & 3u) == 0)
-    hipLaunchKernelGGL(k_spot_moments<true>, dim3(moments_grid((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w,
-                       mask, n, pass, cx, cy, wsum, out);
+    if (g_moments_threads == 1024)
+      hipLaunchKernelGGL((k_spot_moments<true, 1024>), dim3(moments_grid((n + 3) / 4, 1024)), dim3(1024), 0, (hipStream_t)stream,
+                         x, y, w, mask, n, pass, cx, cy, wsum, out);
+    else
+      hipLaunchKernelGGL(k_spot_moments<true>, dim3(moments_grid((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w,
+                         mask, n, pass, cx, cy, wsum, out);
   else
     hipLaunchKernelGGL(k_spot_moments<false>, dim3(grid_for_reduction(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, w, mask,
                        n, pass, cx, cy, wsum, out);
@@ -3174,6 +3203,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 6 && value >= 0 && value <= 2) {
     g_adjoint_lane = value;
+    return RTT_OK;
+  }
+  if (key == 8 && (value == 256 || value == 1024)) {
+    g_moments_threads = value;
     return RTT_OK;
   }
   if (key == 7 && (value == 128 || value == 256)) {
