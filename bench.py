@@ -50,6 +50,9 @@ def parse():
                          "calls of the N > 1 path (RCCL barrier, all-reduce) execute on a one-GPU box")
     ap.add_argument("--step-loop", action="store_true",
                     help="naive_sim workload: one launch per bounce (the reference's loop) instead of the fused bounce loop")
+    ap.add_argument("--two-launches", action="store_true",
+                    help="sample_trace workload: generate the bundle with the sampling kernel, then trace it (two launches) "
+                         "instead of the launch that generates and traces")
     ap.add_argument("--graph", action="store_true",
                     help="singlet workload: capture one simulate() in a HIP graph and replay it per step (launch-bound sizes)")
     ap.add_argument("--tune-rpt", type=int, default=0, help="override rays per lane (1, 2, 4) for experiments")
@@ -283,12 +286,16 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         bundle = ns.CollimatedDisk(radius=4.0, ray_id=0, device=dev,
                                    transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(dev))
         surfaces = 3
-        kernel = "k_sample_bundle + k_trace_seq"
+        kernel = "k_sample_bundle + k_trace_seq" if a.two_launches else "k_trace_seq<generate>"
         del rays, pos, d
 
         def step():
-            scene.simulate(bundle.sample(n, offset=rank * n, seed=7))
-        bytes_per_ray = 33 + 56
+            fresh = bundle.sample(n, offset=rank * n, seed=7)
+            if a.two_launches:
+                fresh._force()   # (reading the sample generates it)
+            scene.simulate(fresh)
+        # written: traced planes, intensity, id, wavelength (33 B); two launches also write and re-read the sample
+        bytes_per_ray = 33 + 56 if a.two_launches else 33
     elif a.workload == "naive_sim":
         # Scene.simulate() of the 32-surface scene with the reference's default of 100 bounces
         scene = ns.Scene()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTT_ABI_VERSION 4
+#define RTT_ABI_VERSION 5
 #define RTT_MAX_SURFACES 64 /* upper bound on n_surf accepted by every entry point */
 
 /* error codes */
@@ -363,6 +363,20 @@ typedef struct RttSource {
 /* pos, dir: plane triples with leading dimension ld; inten, id, wavelength: [n], each nullable. */
 int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t ld, float* inten, int8_t* id,
                           float* wavelength, int64_t n, void* stream);
+
+/* ---- Bundle.sample(N) followed by SequentialScene.simulate(rays) in one launch ---------------------
+ * (rays/bundle.py:30-37 + scene/sequential.py:12-36; the pair of calls optim/goals.py:150-156 and the reference's
+ * scripts make for every fresh bundle.)  Each lane generates its two rays exactly as rtt_sample_bundle_f32 does for the
+ * same `src` (same Philox blocks, same formulas), traces them as rtt_trace_seq_f32 does and writes the traced planes
+ * together with the ids and wavelengths of the new bundle: 33 B written per ray, nothing read.  The result equals the
+ * two calls made one after the other.  Restrictions: a source that draws two uniforms per ray (kind <=
+ * RTT_SRC_RAYLEIGH, else RTT_E_KIND) and an even src->offset (a lane's pair is one Philox block, else RTT_E_ALIGN);
+ * callers outside them sample first and trace second.  id_out and wavelength_out are nullable; the sensor arguments
+ * are those of rtt_trace_seq_f32. */
+int rtt_sample_trace_seq_f32(const RttSource* src, float* pos_out, float* dir_out, float* inten_out, int64_t ld_out,
+                             int8_t* id_out, float* wavelength_out, int64_t n, const RttSurface* prog_dev,
+                             const RttSurface* prog_host, int n_surf, float* sens_hit, float* sens_w,
+                             uint8_t* sens_mask, int64_t sens_ld, void* stream);
 
 /* ---- per-id spot sizes: Sensor.getSpotSizeParallel_xy (elements/sensor.py:87-176) ---------------
  * Hits are given densely (x, y, w, id per ray; mask != 0 marks a recorded hit, NULL = all).  Group g = id + 128.

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "rtt_spot_groups_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _dbl, _vp, _vp],
     "rtt_render_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp],
     "rtt_sample_bundle_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
+    "rtt_sample_trace_seq_f32": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp],
 }
 EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune",
                                 "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes",

@@ -934,6 +934,142 @@ DI void apply_physics(const RV& S, V3<T> hl, V3<T> d, V3<T> n, V3<T>& nd, T& im,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Source formulas of Bundle.sample (rays/bundle.py:30-171), used by the sampling kernels further down and by the
+// sequential trace that generates its own rays.
+// ------------------------------------------------------------------------------------------------
+// A ray's values must not depend on the kernel these formulas are inlined into (the sampling kernel, or the trace that
+// generates its own rays), so no product here may be contracted with a following sum at the compiler's discretion
+// (the build allows contraction everywhere): pr() hands a product on as an opaque value, which keeps every operation
+// the individually rounded one of the reference's torch ops.
+DI float pr(float x) {
+  asm("" : "+v"(x));
+  return x;
+}
+// torch.distributions.Uniform.rsample: low + rand * (high - low)
+DI float uniform_between(float lo, float hi, float u) { return lo + pr(u * (hi - lo)); }
+
+constexpr float kTwoPi = 6.283185307179586f;
+
+DI void sample_local(const RttSource& src, float ua, float ub, V3<float>& p, V3<float>& d) {
+  p = {0.0f, 0.0f, 0.0f};
+  d = {0.0f, 0.0f, 1.0f};
+  switch (src.kind) {
+    case RTT_SRC_DISK: {  // rays/bundle.py:47-56: theta is drawn before r
+      const float theta = uniform_between(src.par[2], src.par[3], ua);
+      const float r = sqrtf(uniform_between(src.par[0], src.par[1], ub));
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      p = {r * cs, r * sn, 0.0f};
+      break;
+    }
+    case RTT_SRC_LINE:  // rays/bundle.py:111-118
+      p.x = uniform_between(src.par[0], src.par[1], ua);
+      break;
+    case RTT_SRC_FAN: {  // rays/bundle.py:136-140
+      const float theta = uniform_between(src.par[0], src.par[1], ua);
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      d = {0.0f, sn, cs};
+      break;
+    }
+    case RTT_SRC_POINT: {  // rays/bundle.py:65-75, :162-171: phi is drawn before theta
+      const float phi = acosf(pr(-2.0f * uniform_between(src.par[0], src.par[1], ua)) + 1.0f);
+      const float theta = uniform_between(src.par[2], src.par[3], ub);
+      float sp, cp, st, ct;
+      sincosf(phi, &sp, &cp);
+      sincosf(theta, &st, &ct);
+      d = {ct * sp, st * sp, cp};
+      break;
+    }
+    case RTT_SRC_GAUSS: {  // rays/beam.py:37-41 with the normals by Box-Muller
+      const float r = sqrtf(-2.0f * logf(1.0f - ua));
+      float sn, cs;
+      sincosf(kTwoPi * ub, &sn, &cs);
+      p = {src.par[0] * (r * cs), src.par[1] * (r * sn), 0.0f};
+      break;
+    }
+    case RTT_SRC_RAYLEIGH: {  // rays/particle.py:111-125
+      const float q = 2.0f - pr(4.0f * ua);
+      const float A = powf(sqrtf(pr(q * q) + 1.0f) - q, 1.0f / 3.0f);
+      const float ct = A - 1.0f / A;
+      const float st = sqrtf(fmaxf(1.0f - pr(ct * ct), 0.0f));
+      float sn, cs;
+      sincosf(kTwoPi * ub, &sn, &cs);
+      d = {st * cs, st * sn, ct};
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+// cosine-weighted hemisphere about +z (rays/panels.py:27-37, rays/particle.py:62-68)
+DI V3<float> lambert_local(float u1, float u2) {
+  const float r = sqrtf(u1);
+  float sn, cs;
+  sincosf(kTwoPi * u2, &sn, &cs);
+  return {r * cs, r * sn, sqrtf(fmaxf(1.0f - u1, 0.0f))};
+}
+
+// the sources that draw four uniforms: (ua, ub) place the ray, (uc, ud) aim it
+DI void sample_local_wide(const RttSource& src, float ua, float ub, float uc, float ud, V3<float>& p, V3<float>& d) {
+  if (src.kind == RTT_SRC_SPHERE) {  // rays/particle.py:34-87
+    const float ct = pr(2.0f * ua) - 1.0f;
+    const float st = sqrtf(fmaxf(1.0f - pr(ct * ct), 0.0f));
+    float sn, cs;
+    sincosf(kTwoPi * ub, &sn, &cs);
+    const V3<float> n = {st * cs, st * sn, ct};
+    p = scale(src.par[0], n);
+    const V3<float> l = lambert_local(uc, ud);
+    const float v = n.z + 1e-10f;
+    const float sg = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);  // torch.sign
+    const float a = -1.0f / (sg + n.z);
+    const float b = n.x * n.y * a;
+    const V3<float> tg = {1.0f + pr(sg * (n.x * n.x) * a), sg * b, -sg * n.x};
+    const V3<float> bt = {b, sg + pr((n.y * n.y) * a), -n.y};
+    d = {pr(l.x * tg.x) + pr(l.y * bt.x) + pr(l.z * n.x), pr(l.x * tg.y) + pr(l.y * bt.y) + pr(l.z * n.y),
+         pr(l.x * tg.z) + pr(l.y * bt.z) + pr(l.z * n.z)};
+    return;
+  }
+  RttSource part = src;  // RTT_SRC_PANEL: an area sampler and an emission model, each a two-uniform source
+  V3<float> unused;
+  if (src.area_kind == RTT_AREA_RING) {
+    part.kind = RTT_SRC_DISK;
+    sample_local(part, ua, ub, p, unused);
+  } else {  // rays/panels.py:118-122
+    p = {uniform_between(src.par[0], src.par[1], ua), uniform_between(src.par[2], src.par[3], ub), 0.0f};
+  }
+  if (src.emit_kind == RTT_EMIT_CONE) {  // rays/panels.py:40-62
+    part.kind = RTT_SRC_POINT;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part.par[k] = src.epar[k];
+    sample_local(part, uc, ud, unused, d);
+  } else {
+    d = lambert_local(uc, ud);
+  }
+}
+
+struct BundleOut {
+  float* __restrict__ pos;
+  float* __restrict__ dir;
+  int64_t ld;
+  float* __restrict__ inten;
+  int8_t* __restrict__ id;
+  float* __restrict__ wavelength;
+};
+
+// local sample -> global ray: RayTransformBundle.transform_ (pos @ R^T + t, dir @ R^T, geom/transform.py:259-262)
+// and F.normalize of Rays.__post_init__ (dir / max(|dir|, 1e-12), rays/ray.py:22-25)
+DI void pose_sampled_ray(const RttSource& src, V3<float> p, V3<float> d, V3<float>& pg, V3<float>& dg) {
+  const float* R = src.R;
+  auto row = [&](V3<float> v, int i) { return pr(v.x * R[3 * i]) + pr(v.y * R[3 * i + 1]) + pr(v.z * R[3 * i + 2]); };
+  pg = {row(p, 0) + src.t[0], row(p, 1) + src.t[1], row(p, 2) + src.t[2]};
+  dg = {row(d, 0), row(d, 1), row(d, 2)};
+  const float len = fmaxf(sqrtf(pr(dg.x * dg.x) + pr(dg.y * dg.y) + pr(dg.z * dg.z)), 1e-12f);
+  dg = {dg.x / len, dg.y / len, dg.z / len};
+}
+
 struct RayIO {
   const float* pos_in;
   const float* dir_in;
@@ -1123,9 +1259,21 @@ DI void visit_seq(const RV& S, Ray<T>& r, const SensorIO& se, I i, int nv) {
 // the bins.  (One row per block took the adding kernel 87 us for the 65536 blocks of a 32 Mi-ray launch.)
 constexpr int kMomBins = 1024;
 
-template <class T, int G, bool LDS_PROG, bool MOM = false>
+// GEN: the rays are not read but generated: lane l of a tile makes the pair of rays with global indices
+// (offset + base + 2l, + 1) from one Philox block, exactly the values k_sample_bundle writes for them, traces them and
+// stores the result together with the ids and wavelengths of the new bundle.  Bundle.sample + simulate then cost
+// 33 B written per ray and nothing read.  The source's offset must be even.
+struct GenIO {
+  RttSource src;
+  int8_t* id;         // [n] or null
+  float* wavelength;  // [n] or null
+};
+
+template <class T, int G, bool LDS_PROG, bool MOM = false, bool GEN = false>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
-                                                      Ops ops, SensorIO se, int vec, double* __restrict__ mom_partials = nullptr) {
+                                                      Ops ops, SensorIO se, int vec, double* __restrict__ mom_partials = nullptr,
+                                                      GenIO gen = GenIO{}) {
+  static_assert(!GEN || (G == 1 && LaneOf<T>::N == 2), "generated rays come in pairs, one pair per lane");
   __shared__ RttSurface lds_prog[LDS_PROG ? RTT_MAX_SURFACES : 1];
   __shared__ double mom_wave[MOM ? 3 * (kBlock / 64) : 1];
   float lane_mom[3] = {0.0f, 0.0f, 0.0f};
@@ -1164,7 +1312,21 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
     const bool whole = vec != 0 && tio.n >= tile;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (whole) {
+      if constexpr (GEN) {
+        // lanes past the end generate the rays that would follow and store nothing
+        const uint64_t first = gen.src.offset + (uint64_t)base + idx[g];
+        const Philox4 rnd = philox4x32_10(first >> 1, gen.src.seed);
+        V3<float> pg[2], dg[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          V3<float> pl, dl;
+          sample_local(gen.src, unit_uniform(rnd.x[2 * h]), unit_uniform(rnd.x[2 * h + 1]), pl, dl);
+          pose_sampled_ray(gen.src, pl, dl, pg[h], dg[h]);
+        }
+        r[g].p = {T{pg[0].x, pg[1].x}, T{pg[0].y, pg[1].y}, T{pg[0].z, pg[1].z}};
+        r[g].d = {T{dg[0].x, dg[1].x}, T{dg[0].y, dg[1].y}, T{dg[0].z, dg[1].z}};
+        r[g].I = splat<T>(1.0f);
+      } else if (whole) {
         r[g] = load_ray<T>(tio, idx[g], true, N);
       } else {
         // lanes past the end (nv == 0) trace a copy of the tile's first ray and store nothing
@@ -1184,6 +1346,20 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
         store_ray<T>(tio, idx[g], r[g], true, N);
       } else if (nv[g]) {
         store_ray<T>(tio, idx[g], r[g], vec != 0, nv[g]);
+      }
+      if constexpr (GEN) {
+        if (nv[g]) {
+          if (gen.wavelength) st_(gen.wavelength + base, idx[g], splat<T>(0.0f), vec != 0, nv[g]);
+          if (gen.id) {
+            int8_t* id = gen.id + base + idx[g];
+            if (vec != 0 && nv[g] == 2) {
+              __builtin_nontemporal_store((uint16_t)((uint8_t)gen.src.ray_id * 0x0101u), reinterpret_cast<uint16_t*>(id));
+            } else {
+              id[0] = (int8_t)gen.src.ray_id;
+              if (nv[g] == 2) id[1] = (int8_t)gen.src.ray_id;
+            }
+          }
+        }
       }
     }
   }
@@ -2153,129 +2329,6 @@ __global__ void __launch_bounds__(kBlock) k_spot_groups(const float* __restrict_
 // indices (2j, 2j+1) from one Philox4x32-10 block, applies the bundle transform and the normalisation
 // of Rays.initialize, and writes the structure-of-arrays planes: a write-only kernel.
 // ------------------------------------------------------------------------------------------------
-// torch.distributions.Uniform.rsample: low + rand * (high - low)
-DI float uniform_between(float lo, float hi, float u) { return lo + u * (hi - lo); }
-
-constexpr float kTwoPi = 6.283185307179586f;
-
-DI void sample_local(const RttSource& src, float ua, float ub, V3<float>& p, V3<float>& d) {
-  p = {0.0f, 0.0f, 0.0f};
-  d = {0.0f, 0.0f, 1.0f};
-  switch (src.kind) {
-    case RTT_SRC_DISK: {  // rays/bundle.py:47-56: theta is drawn before r
-      const float theta = uniform_between(src.par[2], src.par[3], ua);
-      const float r = sqrtf(uniform_between(src.par[0], src.par[1], ub));
-      float sn, cs;
-      sincosf(theta, &sn, &cs);
-      p = {r * cs, r * sn, 0.0f};
-      break;
-    }
-    case RTT_SRC_LINE:  // rays/bundle.py:111-118
-      p.x = uniform_between(src.par[0], src.par[1], ua);
-      break;
-    case RTT_SRC_FAN: {  // rays/bundle.py:136-140
-      const float theta = uniform_between(src.par[0], src.par[1], ua);
-      float sn, cs;
-      sincosf(theta, &sn, &cs);
-      d = {0.0f, sn, cs};
-      break;
-    }
-    case RTT_SRC_POINT: {  // rays/bundle.py:65-75, :162-171: phi is drawn before theta
-      const float phi = acosf(-2.0f * uniform_between(src.par[0], src.par[1], ua) + 1.0f);
-      const float theta = uniform_between(src.par[2], src.par[3], ub);
-      float sp, cp, st, ct;
-      sincosf(phi, &sp, &cp);
-      sincosf(theta, &st, &ct);
-      d = {ct * sp, st * sp, cp};
-      break;
-    }
-    case RTT_SRC_GAUSS: {  // rays/beam.py:37-41 with the normals by Box-Muller
-      const float r = sqrtf(-2.0f * logf(1.0f - ua));
-      float sn, cs;
-      sincosf(kTwoPi * ub, &sn, &cs);
-      p = {src.par[0] * (r * cs), src.par[1] * (r * sn), 0.0f};
-      break;
-    }
-    case RTT_SRC_RAYLEIGH: {  // rays/particle.py:111-125
-      const float q = 2.0f - 4.0f * ua;
-      const float A = powf(sqrtf(q * q + 1.0f) - q, 1.0f / 3.0f);
-      const float ct = A - 1.0f / A;
-      const float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
-      float sn, cs;
-      sincosf(kTwoPi * ub, &sn, &cs);
-      d = {st * cs, st * sn, ct};
-      break;
-    }
-    default:
-      break;
-  }
-}
-
-// cosine-weighted hemisphere about +z (rays/panels.py:27-37, rays/particle.py:62-68)
-DI V3<float> lambert_local(float u1, float u2) {
-  const float r = sqrtf(u1);
-  float sn, cs;
-  sincosf(kTwoPi * u2, &sn, &cs);
-  return {r * cs, r * sn, sqrtf(fmaxf(1.0f - u1, 0.0f))};
-}
-
-// the sources that draw four uniforms: (ua, ub) place the ray, (uc, ud) aim it
-DI void sample_local_wide(const RttSource& src, float ua, float ub, float uc, float ud, V3<float>& p, V3<float>& d) {
-  if (src.kind == RTT_SRC_SPHERE) {  // rays/particle.py:34-87
-    const float ct = 2.0f * ua - 1.0f;
-    const float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
-    float sn, cs;
-    sincosf(kTwoPi * ub, &sn, &cs);
-    const V3<float> n = {st * cs, st * sn, ct};
-    p = scale(src.par[0], n);
-    const V3<float> l = lambert_local(uc, ud);
-    const float v = n.z + 1e-10f;
-    const float sg = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);  // torch.sign
-    const float a = -1.0f / (sg + n.z);
-    const float b = n.x * n.y * a;
-    const V3<float> tg = {1.0f + sg * (n.x * n.x) * a, sg * b, -sg * n.x};
-    const V3<float> bt = {b, sg + (n.y * n.y) * a, -n.y};
-    d = {l.x * tg.x + l.y * bt.x + l.z * n.x, l.x * tg.y + l.y * bt.y + l.z * n.y, l.x * tg.z + l.y * bt.z + l.z * n.z};
-    return;
-  }
-  RttSource part = src;  // RTT_SRC_PANEL: an area sampler and an emission model, each a two-uniform source
-  V3<float> unused;
-  if (src.area_kind == RTT_AREA_RING) {
-    part.kind = RTT_SRC_DISK;
-    sample_local(part, ua, ub, p, unused);
-  } else {  // rays/panels.py:118-122
-    p = {uniform_between(src.par[0], src.par[1], ua), uniform_between(src.par[2], src.par[3], ub), 0.0f};
-  }
-  if (src.emit_kind == RTT_EMIT_CONE) {  // rays/panels.py:40-62
-    part.kind = RTT_SRC_POINT;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) part.par[k] = src.epar[k];
-    sample_local(part, uc, ud, unused, d);
-  } else {
-    d = lambert_local(uc, ud);
-  }
-}
-
-struct BundleOut {
-  float* __restrict__ pos;
-  float* __restrict__ dir;
-  int64_t ld;
-  float* __restrict__ inten;
-  int8_t* __restrict__ id;
-  float* __restrict__ wavelength;
-};
-
-// local sample -> global ray: RayTransformBundle.transform_ (pos @ R^T + t, dir @ R^T, geom/transform.py:259-262)
-// and F.normalize of Rays.__post_init__ (dir / max(|dir|, 1e-12), rays/ray.py:22-25)
-DI void pose_sampled_ray(const RttSource& src, V3<float> p, V3<float> d, V3<float>& pg, V3<float>& dg) {
-  const float* R = src.R;
-  pg = {p.x * R[0] + p.y * R[1] + p.z * R[2] + src.t[0], p.x * R[3] + p.y * R[4] + p.z * R[5] + src.t[1],
-        p.x * R[6] + p.y * R[7] + p.z * R[8] + src.t[2]};
-  dg = {d.x * R[0] + d.y * R[1] + d.z * R[2], d.x * R[3] + d.y * R[4] + d.z * R[5], d.x * R[6] + d.y * R[7] + d.z * R[8]};
-  const float len = fmaxf(sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z), 1e-12f);
-  dg = {dg.x / len, dg.y / len, dg.z / len};
-}
-
 DI void write_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V3<float> pg, V3<float> dg) {
   o.pos[i] = pg.x; o.pos[o.ld + i] = pg.y; o.pos[2 * o.ld + i] = pg.z;
   o.dir[i] = dg.x; o.dir[o.ld + i] = dg.y; o.dir[2 * o.ld + i] = dg.z;
@@ -2592,6 +2645,36 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
     hipLaunchKernelGGL((k_trace_seq<f2, 1, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
   else
     hipLaunchKernelGGL((k_trace_seq<f2, 1, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec);
+  return launch_status();
+}
+
+int rtt_sample_trace_seq_f32(const RttSource* src, float* pos_out, float* dir_out, float* inten_out, int64_t ld_out,
+                             int8_t* id_out, float* wavelength_out, int64_t n, const RttSurface* prog_dev,
+                             const RttSurface* prog_host, int n_surf, float* sens_hit, float* sens_w, uint8_t* sens_mask,
+                             int64_t sens_ld, void* stream) {
+  if (!src || !pos_out || !dir_out || !inten_out || !prog_dev) return RTT_E_NULL;
+  if (n < 0 || ld_out < n) return RTT_E_SIZE;
+  if (src->kind < RTT_SRC_PENCIL || src->kind > RTT_SRC_RAYLEIGH) return RTT_E_KIND;  // two uniforms per ray only
+  if (src->offset & 1u) return RTT_E_ALIGN;  // a lane's pair of rays is one Philox block
+  if (misaligned(pos_out) || misaligned(dir_out) || misaligned(inten_out) || misaligned(wavelength_out) ||
+      misaligned(sens_hit) || misaligned(sens_w))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  if (!prog_host) any_sensor = sens_hit != nullptr;
+  if (any_sensor && (!sens_hit || !sens_w || !sens_mask)) return RTT_E_NULL;
+  if (any_sensor && sens_ld < n) return RTT_E_SIZE;
+  if (n == 0) return RTT_OK;
+  RayIO io = {pos_out, dir_out, inten_out, ld_out, pos_out, dir_out, inten_out, ld_out, n};  // nothing is read
+  SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
+  GenIO gen = {*src, id_out, wavelength_out};
+  const Ops ops = make_ops(prog_host, n_surf);
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (ld_out % 2 == 0) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out) &&
+                  aligned8(wavelength_out) && (reinterpret_cast<uintptr_t>(id_out) & 1u) == 0;
+  hipLaunchKernelGGL((k_trace_seq<f2, 1, false, false, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io,
+                     prog_dev, n_surf, ops, se, vec, (double*)nullptr, gen);
   return launch_status();
 }
 

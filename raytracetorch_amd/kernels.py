@@ -425,11 +425,13 @@ def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: in
                   area_kind: int = 0, emit_kind: int = 0, emit_par=()) -> Rays:
     """Bundle.sample(N) on the device: local sample, bundle pose, normalisation, ids (one write-only kernel).
     `rot` is the 3x3 local->global rotation, `trans` the translation; rays get the Philox values of the
-    global indices offset .. offset+n-1."""
+    global indices offset .. offset+n-1.  The rays are generated when they are first read (`SampledRays`);
+    `SequentialScene.simulate` generates and traces them in one launch."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("sample_bundle generates rays on a HIP device only")
     import ctypes
+    from .rays.ray import SampledRays
     src = N.RttSource()
     src.kind, src.ray_id = int(kind), int(ray_id)
     par = [float(v) for v in par] + [0.0] * (4 - len(par))
@@ -439,17 +441,57 @@ def sample_bundle(kind: int, par, rot, trans, ray_id: int, seed: int, offset: in
     src.R = (ctypes.c_float * 9)(*[float(v) for v in torch.as_tensor(rot, dtype=torch.float32).reshape(-1).tolist()])
     src.t = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(trans, dtype=torch.float32).reshape(-1).tolist()])
     src.seed, src.offset = int(seed) & (2 ** 64 - 1), int(offset)
-    pos = torch.empty((3, n), device=device, dtype=torch.float32)
-    dir_ = torch.empty((3, n), device=device, dtype=torch.float32)
-    inten = torch.empty((n,), device=device, dtype=torch.float32)
-    ids = torch.empty((n,), device=device, dtype=torch.int8)
-    wl = torch.empty((n,), device=device, dtype=torch.float32)
+    return SampledRays.pending(src, int(n), device)
+
+
+def _sample_planes(n, device):
+    return (torch.empty((3, n), device=device, dtype=torch.float32), torch.empty((3, n), device=device, dtype=torch.float32),
+            torch.empty((n,), device=device, dtype=torch.float32), torch.empty((n,), device=device, dtype=torch.int8),
+            torch.empty((n,), device=device, dtype=torch.float32))
+
+
+def generate_sample(pend):
+    """The planes of a pending sample: (pos [3,N], dir [3,N], intensity [N], id [N] int8, wavelength [N])."""
+    import ctypes
+    n, device = pend.n, pend.device
+    pos, dir_, inten, ids, wl = _sample_planes(n, device)
     if n:
         with torch.cuda.device(device):
-            code = N.lib().rtt_sample_bundle_f32(ctypes.addressof(src), N.ptr(pos), N.ptr(dir_), n, N.ptr(inten),
+            code = N.lib().rtt_sample_bundle_f32(ctypes.addressof(pend.src), N.ptr(pos), N.ptr(dir_), n, N.ptr(inten),
                                                  N.ptr(ids), N.ptr(wl), n, N.stream_handle(device))
         N.check(code, "rtt_sample_bundle_f32")
-    return Rays.from_planes(pos, dir_, inten, ids, wl)
+    return pos, dir_, inten, ids, wl
+
+
+def can_generate_in_trace(pend, prog) -> bool:
+    """Whether rtt_sample_trace_seq_f32 takes this sample: a source of two uniforms per ray, an even global offset
+    (a lane's pair of rays is one Philox block), and something to trace."""
+    return pend.n > 0 and prog.shape[0] > 0 and 0 <= pend.src.kind <= 6 and pend.src.offset % 2 == 0
+
+
+def sample_trace_sequential(rays, prog: np.ndarray):
+    """Bundle.sample + SequentialScene.simulate in one launch for `rays` that are still pending (`SampledRays`): fills
+    them with the traced planes and returns the launch's SensorRecord (None for a program without sensor slots)."""
+    import ctypes
+    pend = rays._take()
+    n, dev = pend.n, pend.device
+    pos, dir_, inten, ids, wl = _sample_planes(n, dev)
+    dp = N.DeviceProgram.upload(prog, dev)
+    k = P.n_sensor_slots(prog)
+    if k:
+        rec = SensorRecord(k, n, dev)
+        hit_p, w_p, mask_p = rec.pointers()
+    else:
+        rec, hit_p, w_p, mask_p = None, None, None, None
+    try:
+        code = _call_on(dev, N.lib().rtt_sample_trace_seq_f32, ctypes.addressof(pend.src),
+                        pos.data_ptr(), dir_.data_ptr(), inten.data_ptr(), n, ids.data_ptr(), wl.data_ptr(), n,
+                        dp.dev.data_ptr(), dp.host_ptr, dp.n, hit_p, w_p, mask_p, n, N.stream_handle(dev))
+        if code:
+            N.check(code, "rtt_sample_trace_seq_f32")
+    finally:
+        rays._pos, rays._dir, rays.intensity, rays.id, rays.wavelength = pos, dir_, inten, ids, wl
+    return rec
 
 
 def spot_groups(x, y, w, mask, ids, pass_id: int, centers, norm_ord: float, out: torch.Tensor):

@@ -133,6 +133,75 @@ class Rays:
         return f"Rays(N={len(self)}, device={self.device}, layout=planes[3,N])"
 
 
+class PendingSample:
+    """What a device sampler call would generate: the source description of the C interface, the number of rays and the
+    device."""
+    __slots__ = ("src", "n", "device")
+
+    def __init__(self, src, n, device):
+        self.src, self.n, self.device = src, n, device
+
+
+_SLOTS = {name: Rays.__dict__[name] for name in Rays.__slots__}
+
+
+class SampledRays(Rays):
+    """The rays of a `Bundle.sample(N)` on a HIP device, before anybody has looked at them.  The call has fixed which
+    rays these are (source, pose, Philox key and global offset), but the planes are generated only when they are first
+    read — or never: `SequentialScene.simulate` generates and traces such rays in one launch, which writes the traced
+    planes and reads nothing.  The first access turns the object into plain `Rays`; until then the description sits in
+    the `wavelength` slot, so both classes share one layout."""
+    __slots__ = ()
+
+    @classmethod
+    def pending(cls, src, n, device):
+        r = object.__new__(cls)
+        _SLOTS["wavelength"].__set__(r, PendingSample(src, n, device))
+        return r
+
+    def _pending(self):
+        return _SLOTS["wavelength"].__get__(self)
+
+    def _take(self):
+        """Become plain `Rays` whose slots the caller fills, and hand out the description."""
+        pend = _SLOTS["wavelength"].__get__(self)
+        self.__class__ = Rays
+        return pend
+
+    def _force(self):
+        from .. import kernels as K
+        pend = self._take()
+        self._pos, self._dir, self.intensity, self.id, self.wavelength = K.generate_sample(pend)
+
+    @property
+    def batch_size(self):
+        return torch.Size([_SLOTS["wavelength"].__get__(self).n])
+
+    @property
+    def device(self):
+        return _SLOTS["wavelength"].__get__(self).device
+
+    def __len__(self):
+        return _SLOTS["wavelength"].__get__(self).n
+
+
+def _lazy_slot(name):
+    slot = _SLOTS[name]
+
+    def get(self):
+        self._force()
+        return slot.__get__(self)
+
+    def put(self, v):
+        self._force()
+        slot.__set__(self, v)
+    return property(get, put)
+
+
+for _name in Rays.__slots__:
+    setattr(SampledRays, _name, _lazy_slot(_name))
+
+
 class Paths:
     """Proxy around ``Rays`` that keeps the position of every ray after each update, for visualisation
     (rays/ray.py:100-207).  ``Scene.step`` and ``SequentialScene.simulate`` recognise the wrapper: a bounce of

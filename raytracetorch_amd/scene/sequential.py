@@ -8,7 +8,7 @@ gather / scatter per surface visit.
 import torch.nn as nn
 
 from .. import kernels as K
-from ..rays.ray import Rays
+from ..rays.ray import Rays, SampledRays
 from .base import Scene
 
 
@@ -23,6 +23,16 @@ class SequentialScene(Scene):
         (scene/sequential.py:12-36).  With `out` (a second Rays of the same size) the result goes
         there and `rays` is left untouched."""
         prog = self._program()
+        if type(rays) is SampledRays:
+            # a fresh Bundle.sample whose planes nobody has read: generate and trace in one launch (33 B written per
+            # ray, nothing read) when the result goes back into `rays` and nothing is to be differentiated
+            pend = rays._pending()
+            if out is None and K.can_generate_in_trace(pend, prog) and not self._needs_grad():
+                rec = K.sample_trace_sequential(rays, prog)
+                if rec is not None:
+                    self._deliver_sensor_visits(prog, rays, rec)
+                return rays
+            rays._force()   # plain Rays from here on
         if type(rays) is Rays and not self._needs_grad(rays):
             # the common call: plain rays, nothing to differentiate
             rec = K.trace_sequential_record(rays, prog, out=out)

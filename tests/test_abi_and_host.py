@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in rtt_hip.h but not exported"
     assert set(names) == set(_native.EXPORTS)
-    assert lib.rtt_abi_version() == 4
+    assert lib.rtt_abi_version() == 5
     assert lib.rtt_surface_record_bytes() == 256 == P.RECORD_BYTES
 
 
@@ -113,6 +113,15 @@ def test_entry_points_validate_before_touching_the_gpu():
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 8, 0) == E_KIND
     src.area_kind, src.emit_kind = 1, 1
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 0, 0) == 0
+    # generate-and-trace: two-uniform sources with an even offset only
+    src.kind, src.offset = 7, 0
+    assert lib.rtt_sample_trace_seq_f32(sp, p, p, p, 8, 0, 0, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_KIND
+    src.kind, src.offset = 1, 3
+    assert lib.rtt_sample_trace_seq_f32(sp, p, p, p, 8, 0, 0, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_ALIGN
+    src.offset = 2
+    assert lib.rtt_sample_trace_seq_f32(sp, p, p, p, 4, 0, 0, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_SIZE
+    assert lib.rtt_sample_trace_seq_f32(sp, p, 0, p, 8, 0, 0, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_NULL
+    assert lib.rtt_sample_trace_seq_f32(sp, p, p, p, 8, 0, 0, 0, p, hp, 1, 0, 0, 0, 0, 0) == 0
     assert lib.rtt_strerror(E_KIND).decode().startswith("surface record")
     assert lib.rtt_tune(0, 3) == E_SIZE and lib.rtt_tune(0, 2) == 0
 

@@ -20,5 +20,5 @@ for f in ("gpurun_out/bench_default.json", "gpurun_out/all_workloads.jsonl"):
             d = json.loads(l); r = d["roofline"]
             print(d["config"]["workload"][:24], "rays", d["config"].get("rays_per_gpu"),
                   "kernel_ms %.4f min %.4f step_ms %.4f value %.4g frac %.3f" % (
-                      r["kernel_ms"], r["kernel_ms_min"], d["ms_per_step"], d["value"], r["frac"]))
+                      r["kernel_ms"], r["kernel_ms_min"] or float("nan"), d["ms_per_step"], d["value"], r["frac"]))
 PY
