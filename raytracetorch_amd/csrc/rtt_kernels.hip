@@ -1059,15 +1059,37 @@ struct BundleOut {
   float* __restrict__ wavelength;
 };
 
+// The sources that shine along their own axis (pencil, disk, line, Gaussian beam) give every ray the same global
+// direction, the normalised third column of the pose: the launcher works it out once on the host, with the very
+// operations of pose_direction() below (individually rounded IEEE products, sums, square root and quotients, so the
+// bits are the ones a lane would get), and the kernels take it from their arguments.
+struct PosedAxis {
+  int32_t known;
+  float d[3];
+};
+
+// dir @ R^T, then F.normalize (geom/transform.py:262, rays/ray.py:22-25); also compiled for the host
+template <class Opaque>
+__host__ __device__ inline void pose_direction(const float* R, float dx, float dy, float dz, float out[3], Opaque keep) {
+  float g[3];
+  for (int i = 0; i < 3; ++i) g[i] = keep(keep(dx * R[3 * i]) + keep(dy * R[3 * i + 1])) + keep(dz * R[3 * i + 2]);
+  const float len = fmaxf(sqrtf(keep(keep(g[0] * g[0]) + keep(g[1] * g[1])) + keep(g[2] * g[2])), 1e-12f);
+  for (int i = 0; i < 3; ++i) out[i] = g[i] / len;
+}
+
 // local sample -> global ray: RayTransformBundle.transform_ (pos @ R^T + t, dir @ R^T, geom/transform.py:259-262)
 // and F.normalize of Rays.__post_init__ (dir / max(|dir|, 1e-12), rays/ray.py:22-25)
-DI void pose_sampled_ray(const RttSource& src, V3<float> p, V3<float> d, V3<float>& pg, V3<float>& dg) {
+DI void pose_sampled_ray(const RttSource& src, const PosedAxis& axis, V3<float> p, V3<float> d, V3<float>& pg, V3<float>& dg) {
   const float* R = src.R;
   auto row = [&](V3<float> v, int i) { return pr(v.x * R[3 * i]) + pr(v.y * R[3 * i + 1]) + pr(v.z * R[3 * i + 2]); };
   pg = {row(p, 0) + src.t[0], row(p, 1) + src.t[1], row(p, 2) + src.t[2]};
-  dg = {row(d, 0), row(d, 1), row(d, 2)};
-  const float len = fmaxf(sqrtf(pr(dg.x * dg.x) + pr(dg.y * dg.y) + pr(dg.z * dg.z)), 1e-12f);
-  dg = {dg.x / len, dg.y / len, dg.z / len};
+  if (axis.known) {
+    dg = {axis.d[0], axis.d[1], axis.d[2]};
+    return;
+  }
+  float o[3];
+  pose_direction(R, d.x, d.y, d.z, o, [](float x) { return pr(x); });
+  dg = {o[0], o[1], o[2]};
 }
 
 struct RayIO {
@@ -1265,6 +1287,7 @@ constexpr int kMomBins = 1024;
 // 33 B written per ray and nothing read.  The source's offset must be even.
 struct GenIO {
   RttSource src;
+  PosedAxis axis;
   int8_t* id;         // [n] or null
   float* wavelength;  // [n] or null
 };
@@ -1321,7 +1344,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
         for (int h = 0; h < 2; ++h) {
           V3<float> pl, dl;
           sample_local(gen.src, unit_uniform(rnd.x[2 * h]), unit_uniform(rnd.x[2 * h + 1]), pl, dl);
-          pose_sampled_ray(gen.src, pl, dl, pg[h], dg[h]);
+          pose_sampled_ray(gen.src, gen.axis, pl, dl, pg[h], dg[h]);
         }
         r[g].p = {T{pg[0].x, pg[1].x}, T{pg[0].y, pg[1].y}, T{pg[0].z, pg[1].z}};
         r[g].d = {T{dg[0].x, dg[1].x}, T{dg[0].y, dg[1].y}, T{dg[0].z, dg[1].z}};
@@ -2339,14 +2362,14 @@ DI void write_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V
 
 DI void store_sampled_ray(const RttSource& src, const BundleOut& o, int64_t i, V3<float> p, V3<float> d) {
   V3<float> pg, dg;
-  pose_sampled_ray(src, p, d, pg, dg);
+  pose_sampled_ray(src, PosedAxis{}, p, d, pg, dg);
   write_sampled_ray(src, o, i, pg, dg);
 }
 
 // `vec`: the planes are 8-byte aligned with an even leading dimension and the call starts on an even global index,
 // so the two rays of a lane are one 8-byte, non-temporal store per plane (the bundle is written once and read by
 // another kernel).
-__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, BundleOut o, int64_t n, int vec) {
+__global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, PosedAxis axis, BundleOut o, int64_t n, int vec) {
   const uint64_t first_pair = src.offset >> 1;
   const uint64_t pair = first_pair + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const Philox4 rnd = philox4x32_10(pair, src.seed);
@@ -2358,7 +2381,7 @@ __global__ void __launch_bounds__(kBlock) k_sample_bundle(RttSource src, BundleO
     live[h] = g >= src.offset && g < src.offset + (uint64_t)n;
     V3<float> p, d;
     sample_local(src, unit_uniform(rnd.x[2 * h]), unit_uniform(rnd.x[2 * h + 1]), p, d);
-    pose_sampled_ray(src, p, d, pg[h], dg[h]);
+    pose_sampled_ray(src, axis, p, d, pg[h], dg[h]);
   }
   const int64_t i = (int64_t)(2 * pair - src.offset);  // call index of the lane's first ray (-1 when it is not part of the call)
   if (vec && live[0] && live[1]) {
@@ -2609,6 +2632,20 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) !=
 
 int launch_status() { return hipGetLastError() == hipSuccess ? RTT_OK : RTT_E_LAUNCH; }
 
+// The common direction of a source whose local direction is +z for every ray, computed as a lane would compute it
+// (`volatile` keeps every product and sum individually rounded on the host, whatever contraction the build allows).
+PosedAxis posed_axis(const RttSource& src) {
+  PosedAxis a = {};
+  if (src.kind == RTT_SRC_PENCIL || src.kind == RTT_SRC_DISK || src.kind == RTT_SRC_LINE || src.kind == RTT_SRC_GAUSS) {
+    pose_direction(src.R, 0.0f, 0.0f, 1.0f, a.d, [](float x) {
+      volatile float v = x;
+      return (float)v;
+    });
+    a.known = 1;
+  }
+  return a;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2668,7 +2705,7 @@ int rtt_sample_trace_seq_f32(const RttSource* src, float* pos_out, float* dir_ou
   if (n == 0) return RTT_OK;
   RayIO io = {pos_out, dir_out, inten_out, ld_out, pos_out, dir_out, inten_out, ld_out, n};  // nothing is read
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
-  GenIO gen = {*src, id_out, wavelength_out};
+  GenIO gen = {*src, posed_axis(*src), id_out, wavelength_out};
   const Ops ops = make_ops(prog_host, n_surf);
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_out % 2 == 0) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out) &&
@@ -3241,7 +3278,7 @@ int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t 
   const int vec = (src->offset % 2 == 0) && (ld % 2 == 0) && aligned8(pos) && aligned8(dir) && aligned8(inten) &&
                   aligned8(wavelength) && (reinterpret_cast<uintptr_t>(id) & 1u) == 0;
   hipLaunchKernelGGL(k_sample_bundle, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                     *src, o, n, vec);
+                     *src, posed_axis(*src), o, n, vec);
   return launch_status();
 }
 
