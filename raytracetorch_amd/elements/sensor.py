@@ -34,6 +34,7 @@ class Sensor(Element):
         d["_locs"], d["_inten"], d["_ids"] = [], [], []
         d["_dense"] = []  # (hit planes [3,N], w [N], mask [N] uint8, id [N]) per visit, not yet compacted
         d["_dense_bytes"] = 0
+        d["_pending"] = []  # hit lists of fused bounce loops nobody has waited for yet; always older than `_dense`
 
     # A dense record holds 17 bytes per *ray*, the reference's list entry 17 bytes per *hit*: a sensor that is neither
     # read nor reset for many visits (a long stepping loop) compacts its pending records once they pass this size.
@@ -55,6 +56,21 @@ class Sensor(Element):
         if d["_dense_bytes"] > self._DENSE_LIMIT and len(d["_dense"]) > 1:
             self._flush()
 
+    def _record_pending(self, entries_of):
+        """The crossings of a launch that is still running: `entries_of(self)` gives this sensor's list entries
+        [(locs, w, ids)] once somebody reads them (the first call waits for the device)."""
+        if self._dense:
+            self._flush()   # keeps the order of the entries: what is pending is older than what is dense
+        self._pending.append(entries_of)
+
+    def _resolve_pending(self):
+        pending, self.__dict__["_pending"] = self._pending, []
+        for entries_of in pending:
+            for locs, w, ids in entries_of(self):
+                self._locs.append(locs)
+                self._inten.append(w)
+                self._ids.append(ids)
+
     def _record_hits(self, locs, w, ids):
         """One list entry of already compacted hits (rows in ray order)."""
         self._flush()
@@ -63,6 +79,8 @@ class Sensor(Element):
         self._ids.append(ids)
 
     def _flush(self):
+        if self._pending:
+            self._resolve_pending()
         for hit, w, mask, ids in self._dense:
             m = mask.bool()
             if not bool(m.any()):
@@ -123,6 +141,8 @@ class Sensor(Element):
 
     def _hit_records(self):
         """(x, y, w, mask or None, id) device arrays of every recorded visit, dense or compacted."""
+        if self._pending:
+            self._resolve_pending()
         recs = [(hit[0], hit[1], w, mask, ids) for hit, w, mask, ids in self._dense]
         for locs, w, ids in zip(self._locs, self._inten, self._ids):
             recs.append((locs[:, 0].contiguous(), locs[:, 1].contiguous(), w.contiguous(), None, ids.contiguous()))

@@ -296,12 +296,54 @@ def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bo
     return winner, sens_hit, sens_w, sens_mask
 
 
+def _launch_simulate_nearest(src, out, dp, n, max_bounces, bounces, cap, dev):
+    """One launch of the fused bounce loop from the planes `src` into the planes `out` (both (pos, dir, intensity));
+    returns the append list (hit [cap,4], keys [cap,2], count [1]) or Nones for a program without sensors."""
+    has_sensor = cap is not None
+    hit = torch.empty((cap, 4), device=dev, dtype=torch.float32) if has_sensor else None
+    keys = torch.empty((cap, 2), device=dev, dtype=torch.int32) if has_sensor else None
+    count = torch.zeros((1,), device=dev, dtype=torch.int32) if has_sensor else None
+    with torch.cuda.device(dev):
+        code = N.lib().rtt_simulate_nearest_f32(
+            N.ptr(src[0]), N.ptr(src[1]), N.ptr(src[2]), n, N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]), n, n,
+            N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(bounces),
+            N.ptr(hit), N.ptr(keys), N.ptr(count), cap if has_sensor else 0, N.stream_handle(dev))
+    N.check(code, "rtt_simulate_nearest_f32")
+    return hit, keys, count
+
+
+class PendingHits:
+    """The sensor crossings of one fused bounce loop, still as the launch left them: an unsorted append list and its
+    counter in device memory.  Nothing has waited for the launch yet.  `resolve()` reads the count (the first host
+    synchronisation), repeats the launch from the kept input planes with a longer list should the first one have been
+    too short — the rays the loop produced do not depend on the list's capacity, only the list itself is cut — and
+    returns (hit [M,4], keys [M,2])."""
+
+    def __init__(self, src, dp, n, max_bounces, cap, dev, lists):
+        self.src, self.dp, self.n, self.max_bounces, self.cap, self.dev = src, dp, n, max_bounces, cap, dev
+        self.lists = lists
+        self.result = None
+
+    def resolve(self):
+        if self.result is None:
+            hit, keys, count = self.lists
+            m = int(count.item())
+            if m > self.cap:   # more crossings than room: trace again from the untouched input, into scratch planes
+                scratch = tuple(torch.empty_like(t) for t in self.src)
+                hit, keys, count = _launch_simulate_nearest(self.src, scratch, self.dp, self.n, self.max_bounces, None, m, self.dev)
+                m = int(count.item())
+            self.result = (hit[:m], keys[:m])
+            self.src = self.lists = None   # the input planes are no longer needed
+        return self.result
+
+
 def simulate_nearest(rays: Rays, prog: np.ndarray, max_bounces: int, want_bounces: bool = False,
-                     first_capacity: int = None):
-    """Scene.simulate in one launch (every ray runs its own bounce loop in registers), in place.
+                     first_capacity: int = None, defer: bool = False):
+    """Scene.simulate in one launch (every ray runs its own bounce loop in registers); `rays` receives new planes.
     Returns (bounces [N] int32 or None, hits) where hits is None for a program without sensors, else
     (hit [M,4] = hit_local xyz + intensity before the surface, keys [M,2] = (bounce*64 + slot, ray index)),
-    unsorted.  The ray planes are replaced only after the hit list is known to be complete."""
+    unsorted.  With `defer` the call does not wait for the device: hits is a `PendingHits` whose `resolve()` gives
+    the pair."""
     n = _check_rays(rays)
     dev = rays.device
     bounces = torch.zeros((n,), device=dev, dtype=torch.int32) if want_bounces else None
@@ -310,30 +352,15 @@ def simulate_nearest(rays: Rays, prog: np.ndarray, max_bounces: int, want_bounce
         empty = (torch.empty((0, 4), device=dev), torch.empty((0, 2), device=dev, dtype=torch.int32))
         return bounces, (empty if has_sensor else None)
     dp = N.DeviceProgram.upload(prog, dev)
-    out_pos, out_dir, out_int = torch.empty_like(rays._pos), torch.empty_like(rays._dir), torch.empty_like(rays.intensity)
-    cap = (2 * n if first_capacity is None else int(first_capacity)) if has_sensor else 0
-    while True:
-        hit = torch.empty((cap, 4), device=dev, dtype=torch.float32) if has_sensor else None
-        keys = torch.empty((cap, 2), device=dev, dtype=torch.int32) if has_sensor else None
-        count = torch.zeros((1,), device=dev, dtype=torch.int32) if has_sensor else None
-        with torch.cuda.device(dev):
-            code = N.lib().rtt_simulate_nearest_f32(
-                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
-                N.ptr(out_pos), N.ptr(out_dir), N.ptr(out_int), n, n,
-                N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(bounces),
-                N.ptr(hit), N.ptr(keys), N.ptr(count), cap, N.stream_handle(dev))
-        N.check(code, "rtt_simulate_nearest_f32")
-        if not has_sensor:
-            break
-        m = int(count.item())
-        if m <= cap:
-            hit, keys = hit[:m], keys[:m]
-            break
-        cap = m     # more sensor crossings than room: trace again from the untouched input
-        if bounces is not None:
-            bounces.zero_()
-    rays._pos, rays._dir, rays.intensity = out_pos, out_dir, out_int
-    return bounces, ((hit, keys) if has_sensor else None)
+    src = (rays._pos, rays._dir, rays.intensity)
+    out = (torch.empty_like(rays._pos), torch.empty_like(rays._dir), torch.empty_like(rays.intensity))
+    cap = (2 * n if first_capacity is None else int(first_capacity)) if has_sensor else None
+    lists = _launch_simulate_nearest(src, out, dp, n, max_bounces, bounces, cap, dev)
+    rays._pos, rays._dir, rays.intensity = out
+    if not has_sensor:
+        return bounces, None
+    pending = PendingHits(src, dp, n, max_bounces, cap, dev, lists)
+    return bounces, (pending if defer else pending.resolve())
 
 
 def simulate_nearest_tangent(rays: Rays, dp, max_bounces: int, tangents: np.ndarray, first_capacity: int = None,

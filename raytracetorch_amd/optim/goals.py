@@ -152,6 +152,8 @@ class SpotSizeLoss(Goal):
 
     def _sensor_records(self):
         s = self.sensor
+        if s._pending:
+            s._resolve_pending()
         recs = [(hit[0], hit[1], w, mask) for hit, w, mask, _ in s._dense]
         for locs, w in zip(s._locs, s._inten):
             recs.append((locs[:, 0].contiguous(), locs[:, 1].contiguous(), w.contiguous(), None))

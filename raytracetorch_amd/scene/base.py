@@ -220,9 +220,22 @@ class Scene(nn.Module):
         # the whole bounce loop in one launch: a ray that misses or dies is not touched by later bounces, so
         # letting each ray stop on its own gives what the reference's lock-step loop gives
         prog = self._program()
-        _, hits = K.simulate_nearest(self.rays, prog, self.Nbounces, first_capacity=getattr(self, "_hit_capacity", None))
-        if hits is not None:
-            self._deliver_sensor_hits(prog, self.rays, *hits)
+        _, hits = K.simulate_nearest(self.rays, prog, self.Nbounces, first_capacity=getattr(self, "_hit_capacity", None),
+                                     defer=True)
+        if hits is None:
+            return
+        if not isinstance(hits, K.PendingHits):
+            return self._deliver_sensor_hits(prog, self.rays, *hits)
+        # The call returns without waiting for the device.  The launch's crossings become the sensors' list entries
+        # when one of them is read: count, sort and split happen then, once for all sensors of the scene.
+        plan, ids, split = self._slot_plan(prog), self.rays.id, {}
+
+        def entries_of(sensor):
+            if not split:
+                split["entries"] = self._split_sensor_hits(plan, ids, *hits.resolve())
+            return [e[1:] for e in split["entries"] if e[0] is sensor]
+        for el in {id(el): el for _, el, fuzzy in plan if fuzzy is None}.values():
+            el._record_pending(entries_of)
 
     def _has_fuzzy(self) -> bool:
         return any(hasattr(fn, "block_function") for el in self.elements for fn in el.surface_functions)
@@ -245,20 +258,28 @@ class Scene(nn.Module):
     def _deliver_sensor_hits(self, prog, rays, hit, keys):
         """Hand an unsorted hit list to the sensors as the reference's per-bounce list entries: one entry per
         bounce in which the sensor was hit, rows in ray order (elements/sensor.py:35-37 under scene/base.py:213-226)."""
+        for el, locs, w, ids in self._split_sensor_hits(self._slot_plan(prog), rays.id, hit, keys):
+            el._record_hits(locs, w, ids)
+
+    @staticmethod
+    def _split_sensor_hits(plan, ray_ids, hit, keys):
+        """[(sensor, locs [m,3], w [m], ids [m])] in the order the reference appends them: by bounce, then by sensor
+        surface, rows in ray order."""
         if hit.shape[0] == 0:
-            return
+            return []
         # one 64-bit key per row, (bounce, slot) in the high word and the ray in the low one: a single sort gives the
         # order, and the sorted keys give the groups and the rays without a second gather
         key, order = torch.sort((keys[:, 0].to(torch.int64) << 32) | keys[:, 1].to(torch.int64))
         hit = hit[order]
-        ids = rays.id[key & 0xFFFFFFFF]
+        ids = ray_ids[key & 0xFFFFFFFF]
         heads, counts = torch.unique_consecutive(key >> 32, return_counts=True)
         heads, counts = torch.stack([heads, counts]).tolist()
-        slot_of = {k: el for k, el, _ in self._slot_plan(prog)}
-        a = 0
+        slot_of = {k: el for k, el, _ in plan}
+        a, out = 0, []
         for g, c in zip(heads, counts):
-            slot_of[g % P.MAX_SURFACES]._record_hits(hit[a:a + c, :3], hit[a:a + c, 3], ids[a:a + c])
+            out.append((slot_of[g % P.MAX_SURFACES], hit[a:a + c, :3], hit[a:a + c, 3], ids[a:a + c]))
             a += c
+        return out
 
     def ray_cast(self, rays):
         """(hit_mask [N], winner_element_ids [N], winner_surf_ids [N]) or None when nothing is hit

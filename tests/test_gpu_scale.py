@@ -417,3 +417,44 @@ def test_alternating_scenes_without_synchronisation_give_the_same_results_every_
                     assert torch.equal(a, b), f"iteration {it}: result differs from the first run of scene {k}"
     locs, inten, _ = lens_b[1].getHitsTensors()
     assert locs.shape[0] > 0 and not torch.equal(first[0][0], first[1][0])
+
+
+def test_simulate_leaves_the_hit_list_pending_until_a_sensor_is_read(ns):
+    """`Scene.simulate()` returns without waiting for its launch: the sensors hold the launch's crossings as a pending
+    entry, which becomes list entries (in the order of recording, also next to a later `step()`) when one is read, and
+    which `reset()` drops unread."""
+    torch.manual_seed(4)
+    b = ns.CollimatedDisk(radius=3.0, ray_id=2, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -10.0]).to(DEV))
+
+    def build():
+        scene = ns.Scene()
+        for el in (scenes.singlet(ns), ns.Sensor(ns.Disk(20.0, transform=scenes.T(ns, 25.0)))):
+            scene.add_element(el)
+        scene.Nbounces = 6
+        scene.rays = b.sample(5000, seed=9, offset=0)
+        return scene
+
+    a = build()
+    a.simulate()
+    sa = a.elements[-1]
+    assert len(sa._pending) == 1 and not sa._locs and not sa._dense
+    sa.reset()
+    assert not sa._pending and not sa.hitLocs
+    a.rays = b.sample(5000, seed=9, offset=0)
+    a.simulate()
+    first = a.rays.clone()
+    near = ns.CollimatedDisk(radius=3.0, ray_id=2, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, 24.0]).to(DEV))
+    a.rays = near.sample(3000, seed=10, offset=0)
+    a.step()                                   # a dense record behind the pending one: these rays meet the sensor first
+    assert len(sa._pending) == 1 and len(sa._dense) == 1
+    ref = build()
+    _step_loop(ref)
+    sr = ref.elements[-1]
+    assert torch.equal(first._pos, ref.rays._pos)
+    locs = sa.hitLocs
+    assert not sa._pending and not sa._dense and len(locs) == len(sr.hitLocs) + 1
+    for la, lb in zip(locs, sr.hitLocs):
+        assert torch.equal(la, lb)
+    assert locs[-1].shape[0] == 3000
+    x, y, w, m, ids = sa._hit_records()[0]
+    assert (ids == 2).all()
