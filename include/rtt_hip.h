@@ -234,7 +234,9 @@ int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
 
 /* ---- one non-sequential bounce: Scene.step (scene/base.py:180-235) ----------------------------
  * ray_cast + winner dispatch + scatter_update for rays with a hit and intensity > 0.
- * winner (nullable) receives the ray_cast result.  Sensor outputs as in rtt_trace_seq_f32. */
+ * winner (nullable) receives the ray_cast result.  Sensor outputs as in rtt_trace_seq_f32, except that a bounce
+ * writes the mask entry only of rays that went to a sensor: the call clears the mask planes first (with a host copy
+ * of the program; without one the caller passes them zeroed). */
 int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
                          float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                          const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,

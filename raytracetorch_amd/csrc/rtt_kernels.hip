@@ -3038,12 +3038,17 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
       misaligned(sens_w))
     return RTT_E_ALIGN;
   bool any_sensor;
-  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  int n_slots = 0;
+  int rc = check_program(prog_host, n_surf, &any_sensor, &n_slots);
   if (rc != RTT_OK) return rc;
   if (!prog_host) any_sensor = sens_hit != nullptr;
   if (any_sensor && (!sens_hit || !sens_w || !sens_mask)) return RTT_E_NULL;
   if (any_sensor && sens_ld < n) return RTT_E_SIZE;
   if (n == 0) return RTT_OK;
+  // a bounce writes the mask entry only of rays that went to a sensor: the planes start from zero
+  if (prog_host && n_slots > 0 &&
+      hipMemsetAsync(sens_mask, 0, (size_t)n_slots * (size_t)sens_ld, (hipStream_t)stream) != hipSuccess)
+    return RTT_E_LAUNCH;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };

@@ -272,6 +272,31 @@ def ray_cast(rays: Rays, prog: np.ndarray):
     return winner, tmin
 
 
+def step_nearest_record(rays: Rays, prog: np.ndarray):
+    """One Scene.step bounce in place, the plain call (no winners wanted): returns the launch's SensorRecord, or None
+    for a program without sensor slots.  The entry point clears the record's masks itself."""
+    n = _check_rays(rays)
+    k = P.n_sensor_slots(prog)
+    dev = rays.device
+    if n == 0 or prog.shape[0] == 0:
+        rec = SensorRecord(k, n, dev) if k else None
+        if rec is not None:
+            rec.views()[2].zero_()
+        return rec
+    dp = N.DeviceProgram.upload(prog, dev)
+    if k:
+        rec = SensorRecord(k, n, dev)
+        hit_p, w_p, mask_p = rec.pointers()
+    else:
+        rec, hit_p, w_p, mask_p = None, None, None, None
+    pos, d, inten = rays._pos.data_ptr(), rays._dir.data_ptr(), rays.intensity.data_ptr()
+    code = _call_on(dev, N.lib().rtt_step_nearest_f32, pos, d, inten, n, pos, d, inten, n, n,
+                    dp.dev.data_ptr(), dp.host_ptr, dp.n, None, hit_p, w_p, mask_p, n, N.stream_handle(dev))
+    if code:
+        N.check(code, "rtt_step_nearest_f32")
+    return rec
+
+
 def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bool = False):
     """One Scene.step bounce on the device (in place by default)."""
     n = _check_rays(rays)
@@ -280,9 +305,10 @@ def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bo
     elif _check_rays(out) != n:
         raise ValueError("`out` must hold the same number of rays")
     dev = rays.device
-    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev)
+    launches = bool(n and prog.shape[0])
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev, zero_mask=not launches)   # the entry point clears the masks
     winner = torch.full((n,), -1, device=dev, dtype=torch.int32) if want_winner else None
-    if n and prog.shape[0]:
+    if launches:
         dp = N.DeviceProgram.upload(prog, dev)
         with torch.cuda.device(dev):
             code = N.lib().rtt_step_nearest_f32(

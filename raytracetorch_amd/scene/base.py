@@ -312,6 +312,12 @@ class Scene(nn.Module):
                 self.rays._snapshot()
             return
         prog = self._program()
+        if not recording and type(raw) is Rays:
+            # the common call: plain rays in place, nobody asks for the winners
+            rec = K.step_nearest_record(raw, prog)
+            if rec is not None:
+                self._deliver_sensor_visits(prog, raw, rec)
+            return
         lit = raw.intensity > 0 if recording else None
         winner, sens_hit, sens_w, sens_mask = K.step_nearest(raw, prog, want_winner=recording)
         self._deliver_sensor_records(prog, raw, sens_hit, sens_w, sens_mask)
