@@ -267,6 +267,21 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
                              int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
                              int64_t hit_capacity, void* stream);
 
+/* The same loop run in stages of a few bounces (scene/base.py:129-142): after each stage the rays that still move are
+ * packed into compact planes for the next one and the rays that have come to rest are written to their places, so
+ * wavefronts stay full of moving rays however unevenly a bundle thins out.  Same outputs as rtt_simulate_nearest_f32,
+ * bit for bit (a ray's arithmetic does not depend on the rays it shares a wavefront with).  Needs a host copy of the
+ * program, output planes distinct from the input planes (RTT_E_ALIGN), a program without RTT_PHYS_FRESNEL (its draws
+ * are keyed by the place in the launch: RTT_E_KIND) and a 256-byte aligned device workspace of
+ * rtt_simulate_nearest_staged_workspace_bytes(n) bytes.  Pays off for bundles of many rays and loops of many bounces;
+ * for a few thousand rays the single launch is faster. */
+int64_t rtt_simulate_nearest_staged_workspace_bytes(int64_t n);
+int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                                    float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                                    const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
+                                    int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
+                                    int64_t hit_capacity, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Scene.simulate carrying derivatives (the reference gets them from torch autograd through scene/base.py:129-235;
  * optim/goals.py:63-96 relies on that): the bounce loop above where every ray is a dual number over n_theta (2, 4,
  * 6 or 8) parameter directions given by the tangent table tan_dev [n_surf][32][n_theta] (layout as for

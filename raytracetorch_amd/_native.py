@@ -47,6 +47,8 @@ _SIGNATURES = {
     "rtt_spot_moments_f32": [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _dbl, _dbl, _vp, _vp],
     "rtt_simulate_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                  _vp, _vp, _vp, _vp, _i64, _vp],
+    "rtt_simulate_nearest_staged_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
+                                        _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     "rtt_simulate_nearest_tangent_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                          _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "rtt_trace_seq_ray_adjoint_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
@@ -58,7 +60,7 @@ _SIGNATURES = {
 }
 EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune",
                                 "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes",
-                                "rtt_trace_seq_moments_workspace_bytes")
+                                "rtt_trace_seq_moments_workspace_bytes", "rtt_simulate_nearest_staged_workspace_bytes")
 
 
 class RttSource(ctypes.Structure):
@@ -102,6 +104,8 @@ def lib():
     L.rtt_trace_seq_adjoint_workspace_bytes.restype = _i64
     L.rtt_trace_seq_moments_workspace_bytes.argtypes = [_i64]
     L.rtt_trace_seq_moments_workspace_bytes.restype = _i64
+    L.rtt_simulate_nearest_staged_workspace_bytes.argtypes = [_i64]
+    L.rtt_simulate_nearest_staged_workspace_bytes.restype = _i64
     if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
         raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")
     _lib = L

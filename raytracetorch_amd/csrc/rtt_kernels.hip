@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include "rtt_hip.h"
@@ -1118,6 +1119,8 @@ struct SensorIO {
   // first spot moments on the side (dense mode): lane_mom[0..2] += w, w x, w y of the lane's lit hits on slot mom_slot
   float* lane_mom;
   int32_t mom_slot;
+  // append mode when the launch holds a compacted subset of the call's rays: the keys of the lane's rays
+  int32_t use_lane_key, lane_key[2];
 };
 
 DI float hsum(float v) { return v; }
@@ -1200,7 +1203,7 @@ DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, 
         h[2] = comp(hl.z, k);
         h[3] = comp(I, k);
         se.app_key[2 * (int64_t)at] = se.bounce * RTT_MAX_SURFACES + slot;
-        se.app_key[2 * (int64_t)at + 1] = (int32_t)(se.index0 + (int64_t)i + k);
+        se.app_key[2 * (int64_t)at + 1] = se.use_lane_key ? se.lane_key[k] : (int32_t)(se.index0 + (int64_t)i + k);
       }
     }
     return;
@@ -1637,26 +1640,21 @@ template <class T>
 struct SphereTerms {
   T a, b, cc;
 };
-template <class T>
-DI SphereTerms<T> sphere_terms(V3<T> p, V3<T> d, float cx, float cy, float cz, float R) {
-  const V3<T> oc = {cx - p.x, cy - p.y, cz - p.z};
-  return {dot3(d, d), dot3(oc, d), dot3(oc, oc) - R * R};
-}
 // Sort key: b - R, a lower bound of the entry distance for a unit direction (any point q of the sphere on the
 // ray has t = b + (q - c).d >= b - R).  Only the visiting order depends on it.
 // Skip test: true when no point of the sphere can give this ray a distance <= tmin, i.e. the origin is
 // outside, the direction is a direction (dead rays carry d = 0), and the ray either misses the sphere or
-// enters it beyond tmin (with a margin that covers the rounding of these products): entry > tm  <=>
-// u = b - tm a > 0 and u^2 > disc.  NaN anywhere makes the comparisons false, so the element is tested.
+// enters it beyond tm (tmin with a margin that covers the rounding of these products): entry > tm  <=>
+// u = b - tm a > 0 and u^2 > disc.  NaN anywhere makes the comparisons false, so the element is tested.  The caller
+// rules out rays without a direction.
 template <class T>
-DI typename LaneOf<T>::M sphere_beyond(const SphereTerms<T>& q, T tmin) {
+DI typename LaneOf<T>::M sphere_beyond(const SphereTerms<T>& q, T tm) {
   const T zero = splat<T>(0.0f);
   const T disc = q.b * q.b - q.a * q.cc;
-  const T tm = tmin * 1.0001f + 1e-3f;
   const T u = q.b - tm * q.a;
   const auto misses = or_(lt(disc, zero), le(q.b, zero));
   const auto beyond = and_(gt(u, zero), gt(u * u, disc));
-  return and_(and_(gt(q.cc, zero), gt(q.a, splat<T>(1e-12f))), or_(misses, beyond));
+  return and_(gt(q.cc, zero), or_(misses, beyond));
 }
 
 DI float first_comp(float v) { return v; }
@@ -1726,12 +1724,27 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const CullLanes
     // lane k receives the element of rank k
     const float sR = push_f(rank, L.R), sx = push_f(rank, L.cx), sy = push_f(rank, L.cy), sz = push_f(rank, L.cz);
     const int sfc = __builtin_amdgcn_ds_permute(rank << 2, L.fc);
+    // Per call: |d|^2, |d| with a margin for its rounding, and the rays that cannot be culled at all (a dead ray,
+    // d = 0, "hits" wherever its origin passes the bounds; a ray that takes no part holds no element back).
+    const T zero = splat<T>(0.0f);
+    const T a = dot3(d, d);
+    const T len = sqrt_(a) * 1.0001f;
+    auto cullable = gt(a, splat<T>(1e-12f));
     for (int k = 0; k < L.n; ++k) {
       const float R = lane_f(sR, k);
       if (R >= 0.0f) {
-        const SphereTerms<T> q = sphere_terms(p, d, lane_f(sx, k), lane_f(sy, k), lane_f(sz, k), R);
-        auto beyond = sphere_beyond(q, tmin);
-        if (use_act) beyond = or_(beyond, not_(act));
+        const V3<T> oc = {lane_f(sx, k) - p.x, lane_f(sy, k) - p.y, lane_f(sz, k) - p.z};
+        const T b = dot3(oc, d);
+        const T tm = tmin * 1.0001f + 1e-3f;  // margin for the rounding of these products
+        // Quick test first: a point of the sphere on the ray has (b - R |d|) / |d|^2 <= t <= (b + R |d|) / |d|^2, so the
+        // sphere lies beyond tm when b - R |d| > tm |d|^2 and behind the origin when b + R |d| < 0.  In a train of
+        // elements along an axis that settles all but the neighbours of the ray's position.
+        const T reach = R * len;
+        auto out = and_(cullable, or_(gt(b - reach, tm * a), lt(b + reach, zero)));
+        if (use_act) out = or_(out, not_(act));
+        if (__all(all_(out))) continue;
+        const SphereTerms<T> q = {a, b, dot3(oc, oc) - R * R};
+        auto beyond = or_(out, and_(cullable, sphere_beyond(q, tm)));
         if (__all(all_(beyond))) continue;
       }
       const int fc = lane_i(sfc, k);
@@ -1834,31 +1847,66 @@ DI void serve_winners(const RttSurface* __restrict__ prog, int opv, typename Win
 // simulate instead of per bounce; sensor hits go to an append list keyed by (bounce, slot, ray).
 // Scene.step (scene/base.py:180-235) is the same kernel with max_bounces = 1, dense sensor slots and the
 // winners of the cast written out, so a loop of steps and one simulate run the same machine code per bounce.
-template <class T, bool SINGLE>
+// STAGE: one stage of a bounce loop that is run a few bounces at a time.  After a handful of bounces most rays of a
+// bundle have left the scene or died while a few keep going, and a wavefront pays for a bounce as long as one of its
+// rays moves.  A stage reads its rays from compact planes (the first one from the caller's planes), runs up to
+// max_bounces_ bounces, then hands every ray that still moves on to the compact planes of the next stage (one atomic
+// per wavefront for the places) and writes every ray that has come to rest to its place in the caller's output
+// planes.  A ray carries its index in the call (sensor keys, final place) and its bounce count with it; its arithmetic
+// does not depend on the rays it shares a wavefront with, so the result is that of the single loop bit for bit.
+struct StageIO {
+  const int32_t* count_in;  // device: number of rays in the compact input; null = the io.n rays of the call, in order
+  const int32_t* orig_in;   // [count] index in the call of each ray (null = its position)
+  const int32_t* taken_in;  // [count] bounces taken before this stage (null = 0)
+  float* next_pos;          // compact planes of the next stage, leading dimension next_ld; null in the last stage
+  float* next_dir;
+  float* next_inten;
+  int32_t* next_orig;
+  int32_t* next_taken;
+  int32_t* next_count;      // device counter of the next stage, zero at launch
+  int64_t next_ld;
+  int32_t bounce0;          // bounces of the loop that lie before this stage
+};
+
+template <class T, bool SINGLE, bool STAGE = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                              Ops ops, Cull cull, int max_bounces_,
                                                              int32_t* __restrict__ winner,
-                                                             int32_t* __restrict__ bounces_out, SensorIO se, int vec) {
+                                                             int32_t* __restrict__ bounces_out, SensorIO se, int vec,
+                                                             StageIO st = StageIO{}) {
   constexpr int N = LaneOf<T>::N;
   using M = typename LaneOf<T>::M;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
-  const int64_t rounds = (io.n + stride - 1) / stride;
+  const int64_t n_in = (STAGE && st.count_in) ? (int64_t)*st.count_in : io.n;
+  const int64_t rounds = (n_in + stride - 1) / stride;
   const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t rnd = 0; rnd < rounds; ++rnd) {
     const int64_t want = rnd * stride + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N;
-    const bool live = want < io.n;
+    const bool live = want < n_in;
     const int64_t i = live ? want : 0;
-    const int nv = (io.n - i) >= N ? N : 1;
+    const int nv = (n_in - i) >= N ? N : 1;
     Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
     bool open[N];   // the ray may still move: it has not missed yet
     int taken[N];
+    int orig[N];    // STAGE: index of the ray in the call
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       open[k] = live && k < nv;
       taken[k] = 0;
+      orig[k] = (int)(i + k);
+      if (STAGE) {
+        const int64_t at = i + (k < nv ? k : 0);
+        if (st.orig_in) orig[k] = st.orig_in[at];
+        if (st.taken_in) taken[k] = st.taken_in[at];
+      }
     }
     SensorIO seb = se;
+    if (STAGE) {
+      seb.use_lane_key = 1;
+#pragma unroll
+      for (int k = 0; k < N; ++k) seb.lane_key[k] = orig[k];
+    }
     const int max_bounces = SINGLE ? 1 : max_bounces_;  // SINGLE: Scene.step, the loop folds away
     for (int b = 0; b < max_bounces; ++b) {
       M act = mask_all<M>(false);
@@ -1875,7 +1923,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
       // when the cast result is wanted for every ray (also those without intensity), no ray is left out of
       // the culling decisions
       nearest<T>(prog, n_surf, cl, r.p, r.d, tmin, win, 0, act, !(winner && b == 0));
-      seb.bounce = b;
+      seb.bounce = (STAGE ? st.bounce0 : 0) + b;
       if (winner && b == 0 && live) {  // Scene.ray_cast result of the first bounce, for every ray
 #pragma unroll
         for (int k = 0; k < N; ++k)
@@ -1891,6 +1939,36 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         taken[k] += (a && won) ? 1 : 0;
       }
       serve_winners<T>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
+    }
+    if (STAGE) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const bool mine = live && k < nv;
+        const bool go_on = mine && st.next_pos != nullptr && open[k] && comp(r.I, k) > 0.0f;
+        const int at = append_slot(st.next_count, go_on);  // every lane of the wavefront is here
+        if (go_on) {
+          st.next_pos[at] = comp(r.p.x, k);
+          st.next_pos[st.next_ld + at] = comp(r.p.y, k);
+          st.next_pos[2 * st.next_ld + at] = comp(r.p.z, k);
+          st.next_dir[at] = comp(r.d.x, k);
+          st.next_dir[st.next_ld + at] = comp(r.d.y, k);
+          st.next_dir[2 * st.next_ld + at] = comp(r.d.z, k);
+          st.next_inten[at] = comp(r.I, k);
+          st.next_orig[at] = orig[k];
+          st.next_taken[at] = taken[k];
+        } else if (mine) {
+          const int64_t o = orig[k];
+          io.pos_out[o] = comp(r.p.x, k);
+          io.pos_out[io.ld_out + o] = comp(r.p.y, k);
+          io.pos_out[2 * io.ld_out + o] = comp(r.p.z, k);
+          io.dir_out[o] = comp(r.d.x, k);
+          io.dir_out[io.ld_out + o] = comp(r.d.y, k);
+          io.dir_out[2 * io.ld_out + o] = comp(r.d.z, k);
+          io.inten_out[o] = comp(r.I, k);
+          if (bounces_out) bounces_out[o] = taken[k];
+        }
+      }
+      continue;
     }
     if (!live) continue;
     store_ray<T>(io, i, r, vec != 0, nv);
@@ -3191,6 +3269,109 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
                      n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces,
                      se, vec);
   return launch_status();
+}
+
+// workspace of the staged loop: kStageCounters int32 counters, then two sets of compact planes (pos 3, dir 3, intensity,
+// index, bounce count: 9 words per ray) of `cap` rays each, cap = n rounded up to an even number
+int64_t rtt_simulate_nearest_staged_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  const int64_t cap = (n + 1) & ~(int64_t)1;
+  return 256 + 2 * 9 * 4 * cap;
+}
+
+int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                                    float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                                    const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
+                                    int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
+                                    int64_t hit_capacity, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host || !workspace)
+    return RTT_E_NULL;
+  if (n < 0 || n > 0x7fffffff || ld_in < n || ld_out < n || max_bounces < 0 || hit_capacity < 0 ||
+      hit_capacity > 0x7fffffff || workspace_bytes < rtt_simulate_nearest_staged_workspace_bytes(n))
+    return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out) || misaligned(bounces) || misaligned(hit_list) || misaligned(hit_keys) || misaligned(hit_count) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 255u))
+    return RTT_E_ALIGN;
+  if (pos_in == pos_out || dir_in == dir_out || inten_in == inten_out) return RTT_E_ALIGN;  // rays come to rest at different times
+  bool any_sensor;
+  int rc = check_program(prog_host, n_surf, &any_sensor, nullptr);
+  if (rc != RTT_OK) return rc;
+  for (int s = 0; s < n_surf; ++s)
+    if (prog_host[s].phys_kind == RTT_PHYS_FRESNEL) return RTT_E_KIND;  // its draws are keyed by the place in the launch
+  if (any_sensor && (!hit_count || (hit_capacity > 0 && (!hit_list || !hit_keys)))) return RTT_E_NULL;
+  if (n == 0) return RTT_OK;
+  const hipStream_t sm = (hipStream_t)stream;
+  // bounces per stage: while (nearly) every ray still moves a stage boundary only costs; then rays drop out quickly,
+  // later the few that are left stay for long.  Measured on the 32-surface scene at 4 Mi rays x 100 bounces: 6.8 ms with
+  // this schedule, 6.9-7.6 ms with coarser or finer ones, 10.1 ms in one launch
+  static int kStageBounces[48] = {7, 2, 2, 3, 5, 8, 16, 1 << 30};
+  static int kMaxStages = 8;
+  static bool schedule_read = false;
+  if (!schedule_read) {  // RTT_STAGE_BOUNCES="5,2,2,3": another schedule, for experiments (the rest goes into one last stage)
+    schedule_read = true;
+    if (const char* e = getenv("RTT_STAGE_BOUNCES")) {
+      int k = 0;
+      for (const char* q = e; *q && k < 46;) {
+        const int v = atoi(q);
+        if (v > 0) kStageBounces[k++] = v;
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+      kStageBounces[k++] = 1 << 30;
+      kMaxStages = k;
+    }
+  }
+  if (hipMemsetAsync(workspace, 0, 256, sm) != hipSuccess) return RTT_E_LAUNCH;
+  int32_t* counters = (int32_t*)workspace;
+  const int64_t cap = (n + 1) & ~(int64_t)1;
+  float* sets[2] = {(float*)((char*)workspace + 256), (float*)((char*)workspace + 256) + 9 * cap};
+  SensorIO se = {};
+  se.app_hit = hit_list;
+  se.app_key = hit_keys;
+  se.app_count = any_sensor ? hit_count : nullptr;
+  se.app_cap = (int32_t)hit_capacity;
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const Ops ops = make_ops(prog_host, n_surf);
+  const Cull cull = make_cull(prog_host, n_surf);
+  int done = 0;
+  for (int s = 0; s < kMaxStages && done < max_bounces; ++s) {
+    const int todo = kStageBounces[s] < max_bounces - done ? kStageBounces[s] : max_bounces - done;
+    const bool last = done + todo >= max_bounces;
+    RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+    int vec = (ld_in % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in);
+    StageIO st = {};
+    st.bounce0 = done;
+    if (s > 0) {  // the rays the stage before handed on
+      float* in = sets[(s - 1) & 1];
+      io.pos_in = in;
+      io.dir_in = in + 3 * cap;
+      io.inten_in = in + 6 * cap;
+      io.ld_in = cap;
+      vec = 1;
+      st.count_in = counters + s;
+      st.orig_in = (const int32_t*)(in + 7 * cap);
+      st.taken_in = (const int32_t*)(in + 8 * cap);
+    }
+    if (!last) {
+      float* out = sets[s & 1];
+      st.next_pos = out;
+      st.next_dir = out + 3 * cap;
+      st.next_inten = out + 6 * cap;
+      st.next_orig = (int32_t*)(out + 7 * cap);
+      st.next_taken = (int32_t*)(out + 8 * cap);
+      st.next_count = counters + s + 1;
+      st.next_ld = cap;
+    }
+    // the number of rays of a later stage is known on the device only: a bounded grid walks over it
+    int grid = grid_for(n, 2);
+    if (s > 0 && grid > 8192) grid = 8192;
+    hipLaunchKernelGGL((k_simulate_nearest<f2, false, true>), dim3(grid), dim3(kBlock), 0, sm, io, prog_dev, n_surf, ops, cull, todo,
+                       (int32_t*)nullptr, bounces, se, vec, st);
+    if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
+    done += todo;
+  }
+  return RTT_OK;
 }
 
 int rtt_simulate_nearest_tangent_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,

@@ -329,13 +329,28 @@ def _launch_simulate_nearest(src, out, dp, n, max_bounces, bounces, cap, dev):
     hit = torch.empty((cap, 4), device=dev, dtype=torch.float32) if has_sensor else None
     keys = torch.empty((cap, 2), device=dev, dtype=torch.int32) if has_sensor else None
     count = torch.zeros((1,), device=dev, dtype=torch.int32) if has_sensor else None
-    with torch.cuda.device(dev):
-        code = N.lib().rtt_simulate_nearest_f32(
-            N.ptr(src[0]), N.ptr(src[1]), N.ptr(src[2]), n, N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]), n, n,
+    args = (N.ptr(src[0]), N.ptr(src[1]), N.ptr(src[2]), n, N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]), n, n,
             N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(bounces),
-            N.ptr(hit), N.ptr(keys), N.ptr(count), cap if has_sensor else 0, N.stream_handle(dev))
-    N.check(code, "rtt_simulate_nearest_f32")
+            N.ptr(hit), N.ptr(keys), N.ptr(count), cap if has_sensor else 0)
+    with torch.cuda.device(dev):
+        if staged_bounce_loop(n, max_bounces, dp.host):
+            ws_bytes = int(N.lib().rtt_simulate_nearest_staged_workspace_bytes(n))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            code = N.lib().rtt_simulate_nearest_staged_f32(*args, N.ptr(ws), ws_bytes, N.stream_handle(dev))
+            N.check(code, "rtt_simulate_nearest_staged_f32")
+        else:
+            code = N.lib().rtt_simulate_nearest_f32(*args, N.stream_handle(dev))
+            N.check(code, "rtt_simulate_nearest_f32")
     return hit, keys, count
+
+
+STAGED_MIN_RAYS = 1 << 17    # below, the launches of the stages cost more than the thinned-out wavefronts
+
+
+def staged_bounce_loop(n, max_bounces, prog) -> bool:
+    """Whether the bounce loop runs in stages (rays that still move are packed together every few bounces): many rays,
+    more bounces than the first stage holds, and no functor whose random draws are keyed by the place in the launch."""
+    return n >= STAGED_MIN_RAYS and max_bounces > 5 and not bool((prog["phys_kind"] == P.PHYS_FRESNEL).any())
 
 
 class PendingHits:

@@ -113,6 +113,20 @@ def test_entry_points_validate_before_touching_the_gpu():
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 8, 0) == E_KIND
     src.area_kind, src.emit_kind = 1, 1
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 0, 0) == 0
+    # the staged bounce loop: distinct output planes, an aligned workspace of the stated size, no Fresnel surface
+    assert lib.rtt_simulate_nearest_staged_workspace_bytes(7) == 256 + 2 * 9 * 4 * 8
+    big = (ctypes.c_float * 1024)()
+    ws = (ctypes.addressof(big) + 255) & ~255
+    q = p + 128
+    st = lambda *a: lib.rtt_simulate_nearest_staged_f32(*a)
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == 0
+    assert st(p, p, p, 8, p, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == E_ALIGN      # in place
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, ws + 4, 4096, 0) == E_ALIGN
+    assert st(p, p, p, 8, q, q, q, 8, 8, p, hp, 1, 3, 0, 0, 0, 0, 0, ws, 256, 0) == E_SIZE        # workspace too small
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, 0, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == E_NULL        # needs the host copy
+    fres = rec.copy()
+    fres["phys_kind"] = P.PHYS_FRESNEL
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, fres.ctypes.data, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == E_KIND
     # generate-and-trace: two-uniform sources with an even offset only
     src.kind, src.offset = 7, 0
     assert lib.rtt_sample_trace_seq_f32(sp, p, p, p, 8, 0, 0, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_KIND

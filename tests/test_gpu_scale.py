@@ -458,3 +458,40 @@ def test_simulate_leaves_the_hit_list_pending_until_a_sensor_is_read(ns):
     assert locs[-1].shape[0] == 3000
     x, y, w, m, ids = sa._hit_records()[0]
     assert (ids == 2).all()
+
+
+@pytest.mark.parametrize("case,n", [("naive32", 200001), ("cavity", 50000), ("naive32", 1000)])
+def test_staged_bounce_loop_equals_the_single_launch(ns, case, n, monkeypatch):
+    """rtt_simulate_nearest_staged_f32 (rays that still move are packed together every few bounces) against
+    rtt_simulate_nearest_f32 (every ray loops in its lane): rays, bounce counts and the sorted hit list bit for bit,
+    also with a hit list that is too short at first."""
+    from raytracetorch_amd import kernels as K
+    torch.manual_seed(2)
+    T = lambda z: ns.RayTransform(translation=[0.0, 0.0, z])
+    if case == "naive32":
+        els, bounces = scenes.naive32(ns), 100
+        b = ns.CollimatedDisk(radius=4.0, ray_id=0, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -10.0]).to(DEV))
+    else:
+        els, bounces = [ns.SphericalMirror(c1=-0.002, d=0.0, diameter=40.0, transform=T(60.0)),
+                        ns.SphericalMirror(c1=0.002, d=0.0, diameter=40.0, transform=T(-20.0)),
+                        ns.Sensor(ns.Disk(30.0, transform=T(20.0)))], 23
+        b = ns.CollimatedDisk(radius=6.0, ray_id=0, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, 0.0]).to(DEV))
+    scene = ns.Scene()
+    for el in els:
+        scene.add_element(el)
+    prog = scene._program()
+    src = b.sample(n, seed=31, offset=0)
+    src._pos
+    results = []
+    for min_rays in (1 << 40, 1):
+        monkeypatch.setattr(K, "STAGED_MIN_RAYS", min_rays)
+        assert K.staged_bounce_loop(n, bounces, prog) == (min_rays == 1)
+        rays = src.clone()
+        taken, (hit, keys) = K.simulate_nearest(rays, prog, bounces, want_bounces=True, first_capacity=1000 if case == "cavity" else None)
+        order = torch.argsort(keys[:, 0].to(torch.int64) * (n + 1) + keys[:, 1].to(torch.int64))
+        results.append((rays, taken, hit[order], keys[order]))
+    (ra, ta, ha, ka), (rb, tb, hb, kb) = results
+    for x, y in ((ra._pos, rb._pos), (ra._dir, rb._dir), (ra.intensity, rb.intensity)):
+        assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
+    assert torch.equal(ta, tb) and int(ta.max()) > 5
+    assert ka.shape[0] > 0 and torch.equal(ka, kb) and torch.equal(ha, hb)
