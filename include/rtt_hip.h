@@ -259,13 +259,18 @@ int rtt_render_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
  * bounces[i] (nullable) = number of surfaces ray i interacted with.  Sensor hits are appended, in no particular
  * order, to hit_list[k] = (hit_local x, y, z, intensity before the surface) with hit_keys[k] =
  * (bounce * RTT_MAX_SURFACES + sensor_slot, ray index); *hit_count (zeroed by the caller) counts every hit
- * offered, also those beyond hit_capacity, which are dropped: a caller that finds *hit_count > hit_capacity
- * repeats the call with more room.  Sorting the keys restores the reference's order (by bounce, then by ray). */
+ * offered, also those beyond the capacity, which are dropped: a caller that finds a count above its capacity
+ * repeats the call with more room.  Sorting the keys restores the reference's order (by bounce, then by ray).
+ * The list is kept in hit_parts parts (a power of two, 1 .. 64) of hit_capacity / hit_parts entries each: part p
+ * holds entries [p cap_p, p cap_p + min(count_p, cap_p)) and its counter is hit_count[32 p] (one 128-byte line per
+ * counter; the caller zeroes 32 hit_parts int32).  A block appends to part blockIdx mod hit_parts, so the wavefronts
+ * that meet a sensor in the same bounce do not all add to one address (at 4 Mi rays a single counter costs more than
+ * the bounces themselves); one part is right for a few thousand rays. */
 int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
                              int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
-                             int64_t hit_capacity, void* stream);
+                             int64_t hit_capacity, int hit_parts, void* stream);
 
 /* The same loop run in stages of a few bounces (scene/base.py:129-142): after each stage the rays that still move are
  * packed into compact planes for the next one and the rays that have come to rest are written to their places, so
@@ -280,7 +285,8 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
                                     float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
                                     int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
-                                    int64_t hit_capacity, void* workspace, int64_t workspace_bytes, void* stream);
+                                    int64_t hit_capacity, int hit_parts, void* workspace, int64_t workspace_bytes,
+                                    void* stream);
 
 /* Scene.simulate carrying derivatives (the reference gets them from torch autograd through scene/base.py:129-235;
  * optim/goals.py:63-96 relies on that): the bounce loop above where every ray is a dual number over n_theta (2, 4,

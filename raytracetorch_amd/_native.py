@@ -46,9 +46,9 @@ _SIGNATURES = {
     "rtt_apply_physics_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "rtt_spot_moments_f32": [_vp, _vp, _vp, _vp, _i64, _int, _dbl, _dbl, _dbl, _vp, _vp],
     "rtt_simulate_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
-                                 _vp, _vp, _vp, _vp, _i64, _vp],
+                                 _vp, _vp, _vp, _vp, _i64, _int, _vp],
     "rtt_simulate_nearest_staged_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
-                                        _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
+                                        _vp, _vp, _vp, _vp, _i64, _int, _vp, _i64, _vp],
     "rtt_simulate_nearest_tangent_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                          _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "rtt_trace_seq_ray_adjoint_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,

@@ -1116,6 +1116,10 @@ struct SensorIO {
   int32_t* app_key;    // [cap][2]: bounce * RTT_MAX_SURFACES + sensor slot, index of the ray in the call
   int32_t* app_count;  // number of hits offered so far (may exceed cap: the host then retries with more room)
   int32_t app_cap, bounce;
+  // The list may be kept in app_parts + 1 parts (a power of two minus one as a mask, 0 = one list) of app_cap entries
+  // each, part p with its counter at app_count[kHitCounterStride p]: a block appends to part blockIdx & app_parts, so
+  // the thousands of wavefronts that meet a sensor in the same bounce do not all add to one address.
+  int32_t app_parts;
   // first spot moments on the side (dense mode): lane_mom[0..2] += w, w x, w y of the lane's lit hits on slot mom_slot
   float* lane_mom;
   int32_t mom_slot;
@@ -1179,6 +1183,8 @@ DI void store_ray(const RayIO& io, I i, const Ray<T>& r, bool vec = false, int n
 // wavefront (the first offering lane adds the number of offering lanes, every lane takes the base plus its rank
 // among them) instead of one same-address atomic per lane, which serialise.  Lanes that do not offer get -1.  May be
 // called under divergence: only the lanes that reach the call take part.
+constexpr int kHitCounterStride = 32;  // int32 entries between the counters of two parts: one 128-byte line each
+
 DI int append_slot(int32_t* count, bool want) {
   const uint64_t offering = __ballot(want);
   if (!want) return -1;
@@ -1193,10 +1199,12 @@ DI int append_slot(int32_t* count, bool want) {
 template <class T, class M, class IX>
 DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, int nv) {
   if (se.app_count) {
+    const int part = (int)blockIdx.x & se.app_parts;
 #pragma unroll
     for (int k = 0; k < LaneOf<T>::N; ++k) {
-      const int at = append_slot(se.app_count, k < nv && mcomp(hit, k));
+      int at = append_slot(se.app_count + kHitCounterStride * part, k < nv && mcomp(hit, k));
       if (at >= 0 && at < se.app_cap) {
+        at += part * se.app_cap;
         float* h = se.app_hit + 4 * (int64_t)at;
         h[0] = comp(hl.x, k);
         h[1] = comp(hl.y, k);
@@ -1879,11 +1887,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   const int64_t stride = (int64_t)gridDim.x * kBlock * N;
   const int64_t n_in = (STAGE && st.count_in) ? (int64_t)*st.count_in : io.n;
-  const int64_t rounds = (n_in + stride - 1) / stride;
+  // A late stage holds a few thousand rays from all over the scene: packed densely they would fill a handful of
+  // wavefronts, each of which then tests every element in every bounce, one after the other.  Spread over the lanes
+  // of the grid (every 2^shift-th lane holds rays) a wavefront has a few rays and a few elements, and the others run
+  // beside it.  Only while the spread rays still fit the SIMDs at once: beyond that more wavefronts are more work.
+  int shift = 0;
+  if (STAGE && st.count_in)
+    while (shift < 6 && ((n_in + N - 1) / N << (shift + 1)) <= (int64_t)2048 * 64) ++shift;  // up to 2048 wavefronts: no queueing
+  const int64_t rounds = (((n_in + N - 1) / N << shift) * N + stride - 1) / stride;
   const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t rnd = 0; rnd < rounds; ++rnd) {
-    const int64_t want = rnd * stride + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * N;
-    const bool live = want < n_in;
+    const int64_t slot = rnd * (stride / N) + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // lane of the grid, all rounds
+    const int64_t want = (slot >> shift) * N;
+    const bool live = want < n_in && (slot & ((1 << shift) - 1)) == 0;
     const int64_t i = live ? want : 0;
     const int nv = (n_in - i) >= N ? N : 1;
     Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
@@ -1941,12 +1957,37 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
       serve_winners<T>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
     }
     if (STAGE) {
+      // Places in the next stage's planes: one atomic per block (thousands of wavefronts adding to one address take
+      // about 12 ns each, which at 4 Mi rays is more than a bounce costs): the wavefronts leave their counts in LDS,
+      // one thread reserves the block's range, every ray takes the block's base + the counts of the wavefronts and
+      // components before it + its rank in its own ballot.
+      __shared__ int s_count[kBlock / 64][N];
+      __shared__ int s_base;
+      const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+      bool go_on[N];
+      uint64_t going[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        go_on[k] = live && k < nv && st.next_pos != nullptr && open[k] && comp(r.I, k) > 0.0f;
+        going[k] = __ballot(go_on[k]);
+        if (lane == 0) s_count[wv][k] = (int)__popcll(going[k]);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < kBlock / 64; ++w)
+          for (int k = 0; k < N; ++k) total += s_count[w][k];
+        s_base = total ? atomicAdd(st.next_count, total) : 0;
+      }
+      __syncthreads();
+      int before = s_base;
+      for (int w = 0; w < wv; ++w)
+        for (int k = 0; k < N; ++k) before += s_count[w][k];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const bool mine = live && k < nv;
-        const bool go_on = mine && st.next_pos != nullptr && open[k] && comp(r.I, k) > 0.0f;
-        const int at = append_slot(st.next_count, go_on);  // every lane of the wavefront is here
-        if (go_on) {
+        if (go_on[k]) {
+          const int at = before + (int)__popcll(going[k] & ((1ull << lane) - 1ull));
           st.next_pos[at] = comp(r.p.x, k);
           st.next_pos[st.next_ld + at] = comp(r.p.y, k);
           st.next_pos[2 * st.next_ld + at] = comp(r.p.z, k);
@@ -1967,7 +2008,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
           io.inten_out[o] = comp(r.I, k);
           if (bounces_out) bounces_out[o] = taken[k];
         }
+        before += s_count[wv][k];
       }
+      __syncthreads();  // the counts are reused by the block's next round
       continue;
     }
     if (!live) continue;
@@ -3242,11 +3285,12 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
                              int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
-                             int64_t hit_capacity, void* stream) {
+                             int64_t hit_capacity, int hit_parts, void* stream) {
   if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev) return RTT_E_NULL;
   if (n < 0 || n > 0x7fffffff || ld_in < n || ld_out < n || max_bounces < 0 || hit_capacity < 0 ||
       hit_capacity > 0x7fffffff)
     return RTT_E_SIZE;
+  if (hit_parts < 1 || hit_parts > 64 || (hit_parts & (hit_parts - 1))) return RTT_E_SIZE;
   if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
       misaligned(inten_out) || misaligned(bounces) || misaligned(hit_list) || misaligned(hit_keys) || misaligned(hit_count))
     return RTT_E_ALIGN;
@@ -3261,7 +3305,8 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
   se.app_hit = hit_list;
   se.app_key = hit_keys;
   se.app_count = any_sensor ? hit_count : nullptr;
-  se.app_cap = (int32_t)hit_capacity;
+  se.app_cap = (int32_t)(hit_capacity / hit_parts);
+  se.app_parts = hit_parts - 1;
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
@@ -3283,12 +3328,13 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
                                     float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                                     const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int max_bounces,
                                     int32_t* bounces, float* hit_list, int32_t* hit_keys, int32_t* hit_count,
-                                    int64_t hit_capacity, void* workspace, int64_t workspace_bytes, void* stream) {
+                                    int64_t hit_capacity, int hit_parts, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host || !workspace)
     return RTT_E_NULL;
   if (n < 0 || n > 0x7fffffff || ld_in < n || ld_out < n || max_bounces < 0 || hit_capacity < 0 ||
       hit_capacity > 0x7fffffff || workspace_bytes < rtt_simulate_nearest_staged_workspace_bytes(n))
     return RTT_E_SIZE;
+  if (hit_parts < 1 || hit_parts > 64 || (hit_parts & (hit_parts - 1))) return RTT_E_SIZE;
   if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
       misaligned(inten_out) || misaligned(bounces) || misaligned(hit_list) || misaligned(hit_keys) || misaligned(hit_count) ||
       (reinterpret_cast<uintptr_t>(workspace) & 255u))
@@ -3303,8 +3349,8 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
   if (n == 0) return RTT_OK;
   const hipStream_t sm = (hipStream_t)stream;
   // bounces per stage: while (nearly) every ray still moves a stage boundary only costs; then rays drop out quickly,
-  // later the few that are left stay for long.  Measured on the 32-surface scene at 4 Mi rays x 100 bounces: 6.8 ms with
-  // this schedule, 6.9-7.6 ms with coarser or finer ones, 10.1 ms in one launch
+  // later the few that are left stay for long.  Measured on the 32-surface scene at 4 Mi rays x 100 bounces: 3.3 ms with
+  // this schedule, 3.4 ms with finer or coarser ones
   static int kStageBounces[48] = {7, 2, 2, 3, 5, 8, 16, 1 << 30};
   static int kMaxStages = 8;
   static bool schedule_read = false;
@@ -3330,7 +3376,8 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
   se.app_hit = hit_list;
   se.app_key = hit_keys;
   se.app_count = any_sensor ? hit_count : nullptr;
-  se.app_cap = (int32_t)hit_capacity;
+  se.app_cap = (int32_t)(hit_capacity / hit_parts);
+  se.app_parts = hit_parts - 1;
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const Ops ops = make_ops(prog_host, n_surf);
   const Cull cull = make_cull(prog_host, n_surf);

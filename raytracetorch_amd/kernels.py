@@ -322,16 +322,30 @@ def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bo
     return winner, sens_hit, sens_w, sens_mask
 
 
+HIT_COUNTER_STRIDE = 32   # int32 entries between the counters of two parts of the hit list (the C interface's layout)
+
+
+def hit_list_parts(n) -> int:
+    """Parts of the sensor hit list of a fused bounce loop: with many rays, thousands of wavefronts meet a sensor in
+    the same bounce and a single counter makes them queue; a few thousand rays fill only a few blocks, whose parts
+    would overflow for nothing."""
+    return 64 if n >= (1 << 16) else 1
+
+
 def _launch_simulate_nearest(src, out, dp, n, max_bounces, bounces, cap, dev):
     """One launch of the fused bounce loop from the planes `src` into the planes `out` (both (pos, dir, intensity));
-    returns the append list (hit [cap,4], keys [cap,2], count [1]) or Nones for a program without sensors."""
+    returns the append list (hit [parts * cap_p, 4], keys [parts * cap_p, 2], count [parts, 32], parts) or Nones for a
+    program without sensors; `cap` is the capacity of the whole list."""
     has_sensor = cap is not None
+    parts = hit_list_parts(n) if has_sensor else 1
+    if has_sensor:
+        cap = max(parts, (cap + parts - 1) // parts * parts)
     hit = torch.empty((cap, 4), device=dev, dtype=torch.float32) if has_sensor else None
     keys = torch.empty((cap, 2), device=dev, dtype=torch.int32) if has_sensor else None
-    count = torch.zeros((1,), device=dev, dtype=torch.int32) if has_sensor else None
+    count = torch.zeros((parts, HIT_COUNTER_STRIDE), device=dev, dtype=torch.int32) if has_sensor else None
     args = (N.ptr(src[0]), N.ptr(src[1]), N.ptr(src[2]), n, N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]), n, n,
             N.ptr(dp.dev), dp.host_ptr, dp.n, int(max_bounces), N.ptr(bounces),
-            N.ptr(hit), N.ptr(keys), N.ptr(count), cap if has_sensor else 0)
+            N.ptr(hit), N.ptr(keys), N.ptr(count), cap if has_sensor else 0, parts)
     with torch.cuda.device(dev):
         if staged_bounce_loop(n, max_bounces, dp.host):
             ws_bytes = int(N.lib().rtt_simulate_nearest_staged_workspace_bytes(n))
@@ -341,7 +355,7 @@ def _launch_simulate_nearest(src, out, dp, n, max_bounces, bounces, cap, dev):
         else:
             code = N.lib().rtt_simulate_nearest_f32(*args, N.stream_handle(dev))
             N.check(code, "rtt_simulate_nearest_f32")
-    return hit, keys, count
+    return hit, keys, count, parts
 
 
 STAGED_MIN_RAYS = 1 << 17    # below, the launches of the stages cost more than the thinned-out wavefronts
@@ -367,13 +381,27 @@ class PendingHits:
 
     def resolve(self):
         if self.result is None:
-            hit, keys, count = self.lists
-            m = int(count.item())
-            if m > self.cap:   # more crossings than room: trace again from the untouched input, into scratch planes
+            hit, keys, count, parts = self.lists
+            counts = count[:, 0]
+            most = int(counts.max().item())   # the first wait for the launch
+            while most > hit.shape[0] // parts:
+                # a part was too short: trace again from the untouched input, into scratch planes.  Which part a ray
+                # of a later stage appends to depends on the order in which wavefronts finished the stage before, so
+                # the parts get some room beyond the fullest one of the last attempt, and the check is repeated.
                 scratch = tuple(torch.empty_like(t) for t in self.src)
-                hit, keys, count = _launch_simulate_nearest(self.src, scratch, self.dp, self.n, self.max_bounces, None, m, self.dev)
-                m = int(count.item())
-            self.result = (hit[:m], keys[:m])
+                room = most if parts == 1 else most + most // 4 + 64
+                hit, keys, count, parts = _launch_simulate_nearest(self.src, scratch, self.dp, self.n, self.max_bounces, None,
+                                                                   parts * room, self.dev)
+                counts = count[:, 0]
+                most = int(counts.max().item())
+            if parts == 1:
+                m = int(counts[0].item())
+                hit, keys = hit[:m], keys[:m]
+            else:
+                cap_p = hit.shape[0] // parts
+                filled = (torch.arange(cap_p, device=self.dev)[None, :] < counts[:, None]).reshape(-1)
+                hit, keys = hit[filled], keys[filled]
+            self.result = (hit, keys)
             self.src = self.lists = None   # the input planes are no longer needed
         return self.result
 

@@ -119,14 +119,18 @@ def test_entry_points_validate_before_touching_the_gpu():
     ws = (ctypes.addressof(big) + 255) & ~255
     q = p + 128
     st = lambda *a: lib.rtt_simulate_nearest_staged_f32(*a)
-    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == 0
-    assert st(p, p, p, 8, p, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == E_ALIGN      # in place
-    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, ws + 4, 4096, 0) == E_ALIGN
-    assert st(p, p, p, 8, q, q, q, 8, 8, p, hp, 1, 3, 0, 0, 0, 0, 0, ws, 256, 0) == E_SIZE        # workspace too small
-    assert st(p, p, p, 8, q, q, q, 8, 0, p, 0, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == E_NULL        # needs the host copy
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 1, ws, 4096, 0) == 0
+    assert st(p, p, p, 8, p, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 1, ws, 4096, 0) == E_ALIGN      # in place
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 1, ws + 4, 4096, 0) == E_ALIGN
+    assert st(p, p, p, 8, q, q, q, 8, 8, p, hp, 1, 3, 0, 0, 0, 0, 0, 1, ws, 256, 0) == E_SIZE        # workspace too small
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, 0, 1, 3, 0, 0, 0, 0, 0, 1, ws, 4096, 0) == E_NULL        # needs the host copy
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 3, ws, 4096, 0) == E_SIZE       # parts: a power of two
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 128, ws, 4096, 0) == E_SIZE     # at most 64
+    assert lib.rtt_simulate_nearest_f32(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 0, 0) == E_SIZE
+    assert lib.rtt_simulate_nearest_f32(p, p, p, 8, q, q, q, 8, 0, p, hp, 1, 3, 0, 0, 0, 0, 0, 64, 0) == 0
     fres = rec.copy()
     fres["phys_kind"] = P.PHYS_FRESNEL
-    assert st(p, p, p, 8, q, q, q, 8, 0, p, fres.ctypes.data, 1, 3, 0, 0, 0, 0, 0, ws, 4096, 0) == E_KIND
+    assert st(p, p, p, 8, q, q, q, 8, 0, p, fres.ctypes.data, 1, 3, 0, 0, 0, 0, 0, 1, ws, 4096, 0) == E_KIND
     # generate-and-trace: two-uniform sources with an even offset only
     src.kind, src.offset = 7, 0
     assert lib.rtt_sample_trace_seq_f32(sp, p, p, p, 8, 0, 0, 8, p, hp, 1, 0, 0, 0, 0, 0) == E_KIND

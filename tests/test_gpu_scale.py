@@ -460,11 +460,11 @@ def test_simulate_leaves_the_hit_list_pending_until_a_sensor_is_read(ns):
     assert (ids == 2).all()
 
 
-@pytest.mark.parametrize("case,n", [("naive32", 200001), ("cavity", 50000), ("naive32", 1000)])
+@pytest.mark.parametrize("case,n", [("naive32", 200001), ("cavity", 50000), ("cavity", 70000), ("naive32", 1000)])
 def test_staged_bounce_loop_equals_the_single_launch(ns, case, n, monkeypatch):
     """rtt_simulate_nearest_staged_f32 (rays that still move are packed together every few bounces) against
     rtt_simulate_nearest_f32 (every ray loops in its lane): rays, bounce counts and the sorted hit list bit for bit,
-    also with a hit list that is too short at first."""
+    also with a hit list that is too short at first, kept in one part (fewer than 2^16 rays) or in 64."""
     from raytracetorch_amd import kernels as K
     torch.manual_seed(2)
     T = lambda z: ns.RayTransform(translation=[0.0, 0.0, z])
