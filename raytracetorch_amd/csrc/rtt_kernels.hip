@@ -2753,6 +2753,31 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) !=
 
 int launch_status() { return hipGetLastError() == hipSuccess ? RTT_OK : RTT_E_LAUNCH; }
 
+// Bounces per stage of the staged bounce loop; RTT_STAGE_BOUNCES="5,2,2,3" sets another schedule for experiments (what
+// is left after the listed stages goes into one last stage).  Read once, when the first staged call is made.
+struct StageSchedule {
+  int bounces[48];
+  int stages;
+};
+const StageSchedule& stage_schedule() {
+  static const StageSchedule schedule = [] {
+    StageSchedule s = {{7, 2, 2, 3, 5, 8, 16, 1 << 30}, 8};
+    if (const char* e = getenv("RTT_STAGE_BOUNCES")) {
+      int k = 0;
+      for (const char* q = e; *q && k < 46;) {
+        const int v = atoi(q);
+        if (v > 0) s.bounces[k++] = v;
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+      s.bounces[k++] = 1 << 30;
+      s.stages = k;
+    }
+    return s;
+  }();
+  return schedule;
+}
+
 // The common direction of a source whose local direction is +z for every ray, computed as a lane would compute it
 // (`volatile` keeps every product and sum individually rounded on the host, whatever contraction the build allows).
 PosedAxis posed_axis(const RttSource& src) {
@@ -3351,23 +3376,9 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
   // bounces per stage: while (nearly) every ray still moves a stage boundary only costs; then rays drop out quickly,
   // later the few that are left stay for long.  Measured on the 32-surface scene at 4 Mi rays x 100 bounces: 3.3 ms with
   // this schedule, 3.4 ms with finer or coarser ones
-  static int kStageBounces[48] = {7, 2, 2, 3, 5, 8, 16, 1 << 30};
-  static int kMaxStages = 8;
-  static bool schedule_read = false;
-  if (!schedule_read) {  // RTT_STAGE_BOUNCES="5,2,2,3": another schedule, for experiments (the rest goes into one last stage)
-    schedule_read = true;
-    if (const char* e = getenv("RTT_STAGE_BOUNCES")) {
-      int k = 0;
-      for (const char* q = e; *q && k < 46;) {
-        const int v = atoi(q);
-        if (v > 0) kStageBounces[k++] = v;
-        while (*q && *q != ',') ++q;
-        if (*q == ',') ++q;
-      }
-      kStageBounces[k++] = 1 << 30;
-      kMaxStages = k;
-    }
-  }
+  const StageSchedule& schedule = stage_schedule();
+  const int* kStageBounces = schedule.bounces;
+  const int kMaxStages = schedule.stages;
   if (hipMemsetAsync(workspace, 0, 256, sm) != hipSuccess) return RTT_E_LAUNCH;
   int32_t* counters = (int32_t*)workspace;
   const int64_t cap = (n + 1) & ~(int64_t)1;
