@@ -125,7 +125,9 @@ int rtt_trace_seq_f32(const float* pos_in, const float* dir_in, const float* int
  * w > 0, overwritten.  The sums are formed while the hit is in registers (float32 per wavefront, float64 from there on),
  * which saves the pass of rtt_spot_moments_f32 (pass 0) over the record.  workspace: device scratch of
  * rtt_trace_seq_moments_workspace_bytes(n) bytes (24 KB: 1024 bins per sum that the blocks add into with float64
- * atomics; cleared by the call).  The sensor buffers and prog_host are required. */
+ * atomics; cleared by the call).  The sensor buffers and prog_host are required. 
+ * pos_out, dir_out and inten_out may all three be NULL: the traced rays are then not written (a loss that only reads
+ * the sensor saves 28 B per ray). */
 int64_t rtt_trace_seq_moments_workspace_bytes(int64_t n);
 int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
                               float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,

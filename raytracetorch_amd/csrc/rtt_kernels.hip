@@ -1326,8 +1326,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
   const int64_t stride = (int64_t)gridDim.x * tile;
   for (int64_t base = (int64_t)blockIdx.x * tile; base < io.n; base += stride) {
     // the tile's planes are addressed from wave-uniform base pointers with 32-bit lane offsets
+    const bool stores = !(MOM && !io.pos_out);
     const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in,
-                       io.pos_out + base, io.dir_out + base, io.inten_out + base, io.ld_out, io.n - base};
+                       stores ? io.pos_out + base : nullptr, stores ? io.dir_out + base : nullptr,
+                       stores ? io.inten_out + base : nullptr, io.ld_out, io.n - base};
     SensorIO tse = {se.hit ? se.hit + base : nullptr, se.w ? se.w + base : nullptr,
                     se.mask ? se.mask + base : nullptr, se.ld, base};
     tse.lane_mom = MOM ? lane_mom : nullptr;
@@ -1376,7 +1378,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (whole) {
+      if (MOM && !io.pos_out) {
+        // the caller wants the sensor record and its moments only (a loss that never looks at the traced rays)
+      } else if (whole) {
         store_ray<T>(tio, idx[g], r[g], true, N);
       } else if (nv[g]) {
         store_ray<T>(tio, idx[g], r[g], vec != 0, nv[g]);
@@ -2870,9 +2874,11 @@ int rtt_trace_seq_moments_f32(const float* pos_in, const float* dir_in, const fl
                               const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, float* sens_hit,
                               float* sens_w, uint8_t* sens_mask, int64_t sens_ld, int mom_slot, double* mom, void* workspace,
                               int64_t workspace_bytes, void* stream) {
-  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host || !sens_hit || !sens_w ||
-      !sens_mask || !mom || !workspace)
+  const bool no_rays_out = !pos_out && !dir_out && !inten_out;  // all three null: the traced rays are not wanted
+  if (!pos_in || !dir_in || !inten_in || (!no_rays_out && (!pos_out || !dir_out || !inten_out)) || !prog_dev || !prog_host ||
+      !sens_hit || !sens_w || !sens_mask || !mom || !workspace)
     return RTT_E_NULL;
+  if (no_rays_out) ld_out = ld_in;
   if (n < 0 || ld_in < n || ld_out < n || sens_ld < n || mom_slot < 0 || mom_slot >= RTT_MAX_SURFACES) return RTT_E_SIZE;
   if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
       misaligned(inten_out) || misaligned(sens_hit) || misaligned(sens_w) || (reinterpret_cast<uintptr_t>(mom) & 7u) ||

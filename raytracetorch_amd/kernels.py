@@ -151,20 +151,25 @@ def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
     return rec
 
 
-def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=None):
+def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=None, store: bool = True):
     """SequentialScene.simulate on the device.  Writes into `out` (default: in place into `rays`).
     Returns (sens_hit [K,3,N], sens_w [K,N], sens_mask [K,N] uint8) or (None, None, None).
     `moments` = (sensor slot, float64 device tensor of at least 3 entries): the same launch also leaves the first
-    spot-size moments (sum w, sum w x, sum w y over the lit hits of that slot) in the tensor's first three entries."""
+    spot-size moments (sum w, sum w x, sum w y over the lit hits of that slot) in the tensor's first three entries.
+    With `store=False` (moments only) the traced rays are not written: `rays` keeps its planes and `out` is ignored."""
     n = _check_rays(rays)
-    if out is None:
+    if not store:
+        if moments is None:
+            raise ValueError("only the trace that sums moments can leave the traced rays unwritten")
+        out = None
+    elif out is None:
         out = rays
     elif _check_rays(out) != n:
         raise ValueError("`out` must hold the same number of rays")
     dev = rays.device
     sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev, zero_mask=False)
     if n == 0 or prog.shape[0] == 0:
-        if out is not rays:
+        if out is not None and out is not rays:
             out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
         if moments is not None:
             moments[1][:3] = 0.0
@@ -179,7 +184,8 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=Non
         with torch.cuda.device(dev):
             code = N.lib().rtt_trace_seq_moments_f32(
                 N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
-                N.ptr(out._pos), N.ptr(out._dir), N.ptr(out.intensity), n, n,
+                N.ptr(out._pos) if store else None, N.ptr(out._dir) if store else None,
+                N.ptr(out.intensity) if store else None, n, n,
                 N.ptr(dp.dev), dp.host_ptr, dp.n,
                 N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, int(slot), N.ptr(mom), N.ptr(ws), ws_bytes,
                 N.stream_handle(dev))
@@ -562,7 +568,9 @@ def generate_sample(pend):
 def can_generate_in_trace(pend, prog) -> bool:
     """Whether rtt_sample_trace_seq_f32 takes this sample: a source of two uniforms per ray, an even global offset
     (a lane's pair of rays is one Philox block), and something to trace."""
-    return pend.n > 0 and prog.shape[0] > 0 and 0 <= pend.src.kind <= 6 and pend.src.offset % 2 == 0
+    from .rays.ray import PendingSample
+    return (type(pend) is PendingSample and pend.n > 0 and prog.shape[0] > 0 and 0 <= pend.src.kind <= 6
+            and pend.src.offset % 2 == 0)
 
 
 def sample_trace_sequential(rays, prog: np.ndarray):

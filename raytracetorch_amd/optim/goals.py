@@ -135,15 +135,23 @@ class SpotSizeLoss(Goal):
                  and scene.elements[int(r["element_id"])] is self.sensor]
         if len(slots) != 1 or P.n_sensor_slots(prog) != 1:
             return None
+        from ..rays.ray import PendingTrace, SampledRays
         src = Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id, rays.wavelength)
-        out = Rays.from_planes(torch.empty_like(src._pos), torch.empty_like(src._dir), torch.empty_like(src.intensity),
-                               rays.id, rays.wavelength)
         k = slots[0]
         # the trace leaves the first moments of the sensor's hits (W, sum w x, sum w y) beside the record
         mom = torch.zeros(6, device=src.device, dtype=torch.float64)
-        hit, w, mask = K.trace_sequential(src, prog, out=out, moments=(k, mom))
-        scene._deliver_sensor_records(prog, src, hit, w, mask)
-        rays._pos, rays._dir, rays.intensity = out._pos, out._dir, out.intensity
+        if len(src) == 0:
+            out = Rays.from_planes(torch.empty_like(src._pos), torch.empty_like(src._dir), torch.empty_like(src.intensity),
+                                   rays.id, rays.wavelength)
+            hit, w, mask = K.trace_sequential(src, prog, out=out, moments=(k, mom))
+            scene._deliver_sensor_records(prog, src, hit, w, mask, dst=out)
+            rays._pos, rays._dir, rays.intensity = out._pos, out._dir, out.intensity
+        else:
+            # The loss reads the sensor, not the traced bundle: the trace leaves the rays unwritten (28 B per ray) and
+            # `scene.rays` gets them from a repeat of the trace should anybody look at them.
+            hit, w, mask = K.trace_sequential(src, prog, moments=(k, mom), store=False)
+            scene._deliver_sensor_records(prog, src, hit, w, mask)
+            SampledRays.defer(rays, PendingTrace(src, prog, src.id, src.wavelength))
         # the host work of the backward's set-up (parameter list, slot Jacobians) runs while the device traces;
         # "nothing lit reached the sensor" (optim/goals.py:165-167) is read off the first moment, W = 0
         return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,

@@ -141,16 +141,38 @@ class PendingSample:
     def __init__(self, src, n, device):
         self.src, self.n, self.device = src, n, device
 
+    def make(self):
+        from .. import kernels as K
+        return K.generate_sample(self)
+
+
+class PendingTrace:
+    """The result of a sequential trace that has not been written: the input bundle, the packed program of the call
+    (with the keys of its random draws, so the same branches are taken) and the fields a trace leaves alone."""
+    __slots__ = ("src", "prog", "ids", "wavelength", "n", "device")
+
+    def __init__(self, src, prog, ids, wavelength):
+        self.src, self.prog, self.ids, self.wavelength = src, prog, ids, wavelength
+        self.n, self.device = len(src), src.device
+
+    def make(self):
+        from .. import kernels as K
+        out = Rays.from_planes(torch.empty_like(self.src._pos), torch.empty_like(self.src._dir),
+                               torch.empty_like(self.src.intensity), self.ids, self.wavelength)
+        K.trace_sequential_record(self.src, self.prog, out=out)   # the record of this repeat is not delivered to anybody
+        return out._pos, out._dir, out.intensity, self.ids, self.wavelength
+
 
 _SLOTS = {name: Rays.__dict__[name] for name in Rays.__slots__}
 
 
 class SampledRays(Rays):
-    """The rays of a `Bundle.sample(N)` on a HIP device, before anybody has looked at them.  The call has fixed which
-    rays these are (source, pose, Philox key and global offset), but the planes are generated only when they are first
-    read — or never: `SequentialScene.simulate` generates and traces such rays in one launch, which writes the traced
-    planes and reads nothing.  The first access turns the object into plain `Rays`; until then the description sits in
-    the `wavelength` slot, so both classes share one layout."""
+    """Rays whose planes are still to be made.  The rays of a `Bundle.sample(N)` on a HIP device, before anybody has
+    looked at them: the call has fixed which rays these are (source, pose, Philox key and global offset), but the planes
+    are generated only when they are first read — or never: `SequentialScene.simulate` generates and traces such rays in
+    one launch, which writes the traced planes and reads nothing.  Likewise the traced bundle behind a fused spot-size
+    loss, which only reads the sensor (`PendingTrace`).  The first access turns the object into plain `Rays`; until then
+    the description sits in the `wavelength` slot, so both classes share one layout."""
     __slots__ = ()
 
     @classmethod
@@ -158,6 +180,15 @@ class SampledRays(Rays):
         r = object.__new__(cls)
         _SLOTS["wavelength"].__set__(r, PendingSample(src, n, device))
         return r
+
+    @classmethod
+    def defer(cls, rays, pending):
+        """Turn the plain `rays` object into one whose planes `pending.make()` provides when they are first read."""
+        for name in ("_pos", "_dir", "intensity", "id"):
+            _SLOTS[name].__set__(rays, None)
+        _SLOTS["wavelength"].__set__(rays, pending)
+        rays.__class__ = cls
+        return rays
 
     def _pending(self):
         return _SLOTS["wavelength"].__get__(self)
@@ -169,9 +200,8 @@ class SampledRays(Rays):
         return pend
 
     def _force(self):
-        from .. import kernels as K
         pend = self._take()
-        self._pos, self._dir, self.intensity, self.id, self.wavelength = K.generate_sample(pend)
+        self._pos, self._dir, self.intensity, self.id, self.wavelength = pend.make()
 
     @property
     def batch_size(self):

@@ -237,3 +237,48 @@ def test_trace_with_moments_equals_trace_then_moment_pass(ns, n):
                                    N.ptr(ws), ws_bytes, N.stream_handle(DEV))
     assert lib.rtt_trace_seq_moments_f32(*args(1, ws.numel())) == -2     # the program has one sensor slot
     assert lib.rtt_trace_seq_moments_f32(*args(0, ws.numel() - 8)) == -2  # workspace too small
+
+
+def test_fused_spot_loss_leaves_the_traced_rays_to_be_made_on_demand(ns):
+    """The fused spot-size loss reads the sensor only: its trace does not write the traced bundle
+    (rtt_trace_seq_moments_f32 with null ray outputs), and `scene.rays` is traced when somebody reads it.  Loss and
+    gradients are those of the trace that writes everything; the rays, once read, are those of `simulate`."""
+    from raytracetorch_amd.rays.ray import Rays, SampledRays
+    from raytracetorch_amd import kernels as K
+    torch.manual_seed(3)
+    lens, sensor = scenes.spot_system(ns, grads=True)
+    scene = ns.SequentialScene([lens, sensor]).to(DEV)
+    src = scenes.disk_bundle(ns).sample(20001).to(DEV)
+
+    class Resident(torch.nn.Module):
+        def sample(self, _n):
+            return src.clone()
+    loss = ns.SpotSizeLoss(sensor, [Resident()], N_rays=len(src))(scene)
+    loss.backward()
+    assert type(scene.rays) is SampledRays and len(scene.rays) == len(src)
+    grads = [p.grad.clone() for p in scene.parameters() if p.grad is not None]
+    locs, w, _ = sensor.getHitsTensors()
+    # the same through the plain differentiable trace
+    ref_scene = ns.SequentialScene([lens, sensor])
+    for p in scene.parameters():
+        p.grad = None
+    sensor.reset()
+    traced = ref_scene.simulate(src.clone())
+    assert torch.allclose(scene.rays._pos, traced._pos.detach(), rtol=0, atol=0) and type(scene.rays) is Rays
+    assert torch.equal(scene.rays._dir, traced._dir.detach()) and torch.equal(scene.rays.intensity, traced.intensity.detach())
+    locs2, w2, _ = sensor.getHitsTensors()
+    assert torch.equal(locs, locs2.detach()) and torch.equal(w, w2.detach())
+    # moments and record of the launch that leaves the rays unwritten equal those of the launch that writes them
+    prog = scene._program()
+    outs = []
+    for store in (True, False):
+        mom = torch.zeros(6, device=DEV, dtype=torch.float64)
+        rays = src.clone()
+        hit, ww, mask = K.trace_sequential(rays, prog, moments=(0, mom), store=store)
+        outs.append((mom.clone(), hit, ww, mask, rays))
+    (ma, ha, wa, ka, ra), (mb, hb, wb, kb, rb) = outs
+    assert torch.equal(ma, mb) and torch.equal(ka, kb)
+    m = ka[0].bool()
+    assert torch.equal(ha[0][:, m], hb[0][:, m]) and torch.equal(wa[0][m], wb[0][m])
+    assert torch.equal(rb._pos, src._pos) and not torch.equal(ra._pos, src._pos)
+    assert len(grads) >= 4
