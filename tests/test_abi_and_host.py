@@ -392,3 +392,55 @@ def test_program_cache_sees_writes_through_data(ns):
     assert abs(float(scene._program()[0]["geom"][0]) - 0.01) < 1e-7
     scene.invalidate_program()
     assert abs(float(scene._program()[0]["geom"][0]) - 0.01) < 1e-7
+
+
+def test_rays_with_planes_still_to_be_made():
+    """`SampledRays`: size and device are known without making the planes; the first read of any field makes them once
+    and leaves a plain `Rays`; a plain bundle can be turned into a pending one in place (host logic, no GPU)."""
+    from raytracetorch_amd.rays.ray import Rays, SampledRays
+
+    class Pending:
+        n, device, made = 5, torch.device("cpu"), 0
+
+        def make(self):
+            Pending.made += 1
+            return (torch.zeros(3, 5), torch.ones(3, 5), torch.full((5,), 2.0), torch.zeros(5, dtype=torch.int8), torch.zeros(5))
+
+    r = SampledRays.pending(None, 5, torch.device("cpu"))
+    assert type(r) is SampledRays and len(r) == 5 and r.device.type == "cpu" and tuple(r.batch_size) == (5,)
+    assert "N=5" in repr(r) and type(r) is SampledRays            # none of these made anything
+    plain = Rays.from_planes(torch.rand(3, 4), torch.rand(3, 4), torch.ones(4), torch.zeros(4, dtype=torch.int8), torch.zeros(4))
+    same = SampledRays.defer(plain, Pending())
+    assert same is plain and type(plain) is SampledRays and len(plain) == 5 and Pending.made == 0
+    assert tuple(plain.pos.shape) == (5, 3) and type(plain) is Rays and Pending.made == 1
+    assert float(plain.intensity[0]) == 2.0 and plain.id.dtype == torch.int8 and Pending.made == 1
+    other = SampledRays.defer(Rays.from_planes(torch.rand(3, 4), torch.rand(3, 4), torch.ones(4), torch.zeros(4, dtype=torch.int8),
+                                               torch.zeros(4)), Pending())
+    other.intensity = torch.full((5,), 7.0)                       # a write makes the planes first, then replaces the field
+    assert type(other) is Rays and Pending.made == 2 and float(other.intensity[0]) == 7.0 and tuple(other._pos.shape) == (3, 5)
+    clone = SampledRays.defer(Rays.from_planes(torch.rand(3, 4), torch.rand(3, 4), torch.ones(4), torch.zeros(4, dtype=torch.int8),
+                                               torch.zeros(4)), Pending()).clone()
+    assert type(clone) is Rays and len(clone) == 5 and Pending.made == 3
+
+
+def test_sensor_keeps_pending_hit_lists_in_order(ns):
+    """A sensor's entries come out in the order of recording whether a visit is a compacted list, a dense record or
+    the pending hit list of a bounce loop nobody has waited for (host logic, no GPU)."""
+    s = ns.Sensor(ns.Disk(5.0))
+    asked = []
+
+    def entries_of(sensor):
+        asked.append(sensor)
+        return [(torch.full((2, 3), 1.0), torch.ones(2), torch.zeros(2, dtype=torch.int8)),
+                (torch.full((1, 3), 2.0), torch.ones(1), torch.zeros(1, dtype=torch.int8))]
+    s._record_hits(torch.zeros(1, 3), torch.ones(1), torch.zeros(1, dtype=torch.int8))
+    s._record_pending(entries_of)
+    hit = torch.full((3, 4), 3.0)
+    s._record_dense(hit, torch.ones(4), torch.tensor([1, 0, 0, 1], dtype=torch.uint8), torch.zeros(4, dtype=torch.int8))
+    assert len(s._pending) == 1 and not asked
+    locs = s.hitLocs
+    assert asked == [s] and not s._pending and not s._dense
+    assert [float(l[0, 0]) for l in locs] == [0.0, 1.0, 2.0, 3.0] and [l.shape[0] for l in locs] == [1, 2, 1, 2]
+    s._record_pending(entries_of)
+    s.reset()
+    assert not s._pending and len(asked) == 1 and not s.hitLocs
