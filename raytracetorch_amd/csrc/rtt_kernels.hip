@@ -1910,10 +1910,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     bool open[N];   // the ray may still move: it has not missed yet
     int taken[N];
     int orig[N];    // STAGE: index of the ray in the call
+    int last[N];    // STAGE: the surface the ray met last
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       open[k] = live && k < nv;
       taken[k] = 0;
+      last[k] = 0;
       orig[k] = (int)(i + k);
       if (STAGE) {
         const int64_t at = i + (k < nv ? k : 0);
@@ -1957,41 +1959,47 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         if (a && !won) open[k] = false;
         pend = set_mask(pend, k, a && won);
         taken[k] += (a && won) ? 1 : 0;
+        if (STAGE) last[k] = (a && won) ? icomp(win, k) : last[k];
       }
       serve_winners<T>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
     }
     if (STAGE) {
       // Places in the next stage's planes: one atomic per block (thousands of wavefronts adding to one address take
-      // about 12 ns each, which at 4 Mi rays is more than a bounce costs): the wavefronts leave their counts in LDS,
-      // one thread reserves the block's range, every ray takes the block's base + the counts of the wavefronts and
-      // components before it + its rank in its own ballot.
-      __shared__ int s_count[kBlock / 64][N];
+      // about 12 ns each, which at 4 Mi rays is more than a bounce costs), and within the block's range the rays are
+      // laid out by the surface they met last: a counting sort in LDS (count per surface with the rank as the
+      // returned value, prefix over the surfaces by one wavefront, one thread reserves the range).  The wavefronts
+      // of the next stage, which take 128 consecutive rays, then mostly hold rays that sit on one surface instead of
+      // a cross-section of the block.
+      __shared__ int s_hist[RTT_MAX_SURFACES];
       __shared__ int s_base;
-      const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+      const int lane = (int)(threadIdx.x & 63u);
+      if (threadIdx.x < RTT_MAX_SURFACES) s_hist[threadIdx.x] = 0;
+      __syncthreads();
       bool go_on[N];
-      uint64_t going[N];
+      int rank[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         go_on[k] = live && k < nv && st.next_pos != nullptr && open[k] && comp(r.I, k) > 0.0f;
-        going[k] = __ballot(go_on[k]);
-        if (lane == 0) s_count[wv][k] = (int)__popcll(going[k]);
+        rank[k] = go_on[k] ? atomicAdd(&s_hist[last[k] & (RTT_MAX_SURFACES - 1)], 1) : 0;
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        int total = 0;
-        for (int w = 0; w < kBlock / 64; ++w)
-          for (int k = 0; k < N; ++k) total += s_count[w][k];
-        s_base = total ? atomicAdd(st.next_count, total) : 0;
+      if (threadIdx.x < 64) {
+        static_assert(RTT_MAX_SURFACES == 64, "one lane per surface in the prefix");
+        const int c = s_hist[lane];
+        int incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int up = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += up;
+        }
+        s_hist[lane] = incl - c;
+        if (lane == 63) s_base = incl ? atomicAdd(st.next_count, incl) : 0;
       }
       __syncthreads();
-      int before = s_base;
-      for (int w = 0; w < wv; ++w)
-        for (int k = 0; k < N; ++k) before += s_count[w][k];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const bool mine = live && k < nv;
         if (go_on[k]) {
-          const int at = before + (int)__popcll(going[k] & ((1ull << lane) - 1ull));
+          const int at = s_base + s_hist[last[k] & (RTT_MAX_SURFACES - 1)] + rank[k];
           st.next_pos[at] = comp(r.p.x, k);
           st.next_pos[st.next_ld + at] = comp(r.p.y, k);
           st.next_pos[2 * st.next_ld + at] = comp(r.p.z, k);
@@ -2012,7 +2020,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
           io.inten_out[o] = comp(r.I, k);
           if (bounces_out) bounces_out[o] = taken[k];
         }
-        before += s_count[wv][k];
       }
       __syncthreads();  // the counts are reused by the block's next round
       continue;
