@@ -495,3 +495,44 @@ def test_staged_bounce_loop_equals_the_single_launch(ns, case, n, monkeypatch):
         assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
     assert torch.equal(ta, tb) and int(ta.max()) > 5
     assert ka.shape[0] > 0 and torch.equal(ka, kb) and torch.equal(ha, hb)
+
+
+def test_full_size_staged_loop_and_generated_trace_equal_their_plain_forms(ns, monkeypatch):
+    """At the sizes of the benchmarks: the 100-bounce loop of 4 Mi rays over the 32 surfaces in stages against the
+    single launch (rays, bounce counts, number and checksum of the sensor crossings), and sampling + tracing 64 Mi rays
+    in one launch against the two launches (every plane, bit for bit)."""
+    from raytracetorch_amd import kernels as K
+    n = 4 << 20
+    scene = ns.Scene()
+    for el in scenes.naive32(ns):
+        scene.add_element(el)
+    prog = scene._program()
+    b = ns.CollimatedDisk(radius=4.0, ray_id=0, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -10.0]).to(DEV))
+    src = b.sample(n, seed=1000, offset=0)
+    src._pos
+    outs = []
+    for min_rays in (1 << 40, 1):
+        monkeypatch.setattr(K, "STAGED_MIN_RAYS", min_rays)
+        rays = src.clone()
+        taken, (hit, keys) = K.simulate_nearest(rays, prog, 100, want_bounces=True)
+        key = keys[:, 0].to(torch.int64) * (n + 1) + keys[:, 1].to(torch.int64)
+        outs.append((rays, taken, hit.shape[0], int(key.sum()), float(hit.double().sum())))
+        del hit, keys, key
+    (ra, ta, ma, ka, ha), (rb, tb, mb, kb, hb) = outs
+    for x, y in ((ra._pos, rb._pos), (ra._dir, rb._dir), (ra.intensity, rb.intensity)):
+        assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
+    assert torch.equal(ta, tb) and int(ta.max()) == 100 and ma == mb > n // 2 and ka == kb
+    assert abs(ha - hb) <= 1e-9 * abs(ha)          # the same entries summed in another order
+    del outs, ra, rb, ta, tb, src
+    torch.cuda.empty_cache()
+
+    n = 64 << 20
+    seq = ns.SequentialScene([scenes.singlet(ns)])
+    wide = ns.CollimatedDisk(radius=4.0, ray_id=5, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(DEV))
+    one = seq.simulate(wide.sample(n, seed=7, offset=0))
+    two = wide.sample(n, seed=7, offset=0)
+    two._pos
+    seq.simulate(two)
+    for f in ("_pos", "_dir", "intensity", "id", "wavelength"):
+        assert torch.equal(getattr(one, f), getattr(two, f)), f
+    assert int((one.intensity > 0).sum()) > n // 2
