@@ -577,7 +577,7 @@ def sample_trace_sequential(rays, prog: np.ndarray):
     """Bundle.sample + SequentialScene.simulate in one launch for `rays` that are still pending (`SampledRays`): fills
     them with the traced planes and returns the launch's SensorRecord (None for a program without sensor slots)."""
     import ctypes
-    pend = rays._take()
+    pend = rays._pending()
     n, dev = pend.n, pend.device
     pos, dir_, inten, ids, wl = _sample_planes(n, dev)
     dp = N.DeviceProgram.upload(prog, dev)
@@ -587,14 +587,13 @@ def sample_trace_sequential(rays, prog: np.ndarray):
         hit_p, w_p, mask_p = rec.pointers()
     else:
         rec, hit_p, w_p, mask_p = None, None, None, None
-    try:
-        code = _call_on(dev, N.lib().rtt_sample_trace_seq_f32, ctypes.addressof(pend.src),
-                        pos.data_ptr(), dir_.data_ptr(), inten.data_ptr(), n, ids.data_ptr(), wl.data_ptr(), n,
-                        dp.dev.data_ptr(), dp.host_ptr, dp.n, hit_p, w_p, mask_p, n, N.stream_handle(dev))
-        if code:
-            N.check(code, "rtt_sample_trace_seq_f32")
-    finally:
-        rays._pos, rays._dir, rays.intensity, rays.id, rays.wavelength = pos, dir_, inten, ids, wl
+    code = _call_on(dev, N.lib().rtt_sample_trace_seq_f32, ctypes.addressof(pend.src),
+                    pos.data_ptr(), dir_.data_ptr(), inten.data_ptr(), n, ids.data_ptr(), wl.data_ptr(), n,
+                    dp.dev.data_ptr(), dp.host_ptr, dp.n, hit_p, w_p, mask_p, n, N.stream_handle(dev))
+    if code:
+        N.check(code, "rtt_sample_trace_seq_f32")   # raises; `rays` is still the pending sample it was
+    rays._take()
+    rays._pos, rays._dir, rays.intensity, rays.id, rays.wavelength = pos, dir_, inten, ids, wl
     return rec
 
 

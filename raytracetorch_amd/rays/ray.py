@@ -200,8 +200,9 @@ class SampledRays(Rays):
         return pend
 
     def _force(self):
-        pend = self._take()
-        self._pos, self._dir, self.intensity, self.id, self.wavelength = pend.make()
+        planes = self._pending().make()   # should this raise, the object stays the pending bundle it was
+        self._take()
+        self._pos, self._dir, self.intensity, self.id, self.wavelength = planes
 
     @property
     def batch_size(self):
