@@ -37,7 +37,9 @@ for f in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True
         k = short(row["Name"])
         if k and not k.startswith("k_sample_bundle"):
             stats[k] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3}
-steps = min(v["calls"] for v in stats.values()) if stats else 1   # the kernel launched once per step sets the step count
+# the kernel launched once per step sets the step count; a workload whose every kernel is launched several times per
+# step (the stages of the bounce loop) states its step count in RTT_PROFILE_STEPS
+steps = int(os.environ.get("RTT_PROFILE_STEPS", "0")) or (min(v["calls"] for v in stats.values()) if stats else 1)
 kernels, total = {}, 0.0
 for k, cs in counters.items():
     mean = {c: sum(v) / len(v) for c, v in cs.items()}
