@@ -39,6 +39,7 @@ class Sensor(Element):
     # A dense record holds 17 bytes per *ray*, the reference's list entry 17 bytes per *hit*: a sensor that is neither
     # read nor reset for many visits (a long stepping loop) compacts its pending records once they pass this size.
     _DENSE_LIMIT = 4 << 30
+    _PENDING_LIMIT = 8
 
     def _record_dense(self, hit_planes, w, mask, ids):
         self._dense.append((hit_planes, w, mask, ids))
@@ -61,6 +62,10 @@ class Sensor(Element):
         [(locs, w, ids)] once somebody reads them (the first call waits for the device)."""
         if self._dense:
             self._flush()   # keeps the order of the entries: what is pending is older than what is dense
+        if len(self._pending) >= self._PENDING_LIMIT:
+            # a pending entry keeps the launch's whole hit list and its input planes alive: a sensor that is neither read
+            # nor reset over many launches settles the old ones (which waits for them) before it takes another
+            self._resolve_pending()
         self._pending.append(entries_of)
 
     def _resolve_pending(self):

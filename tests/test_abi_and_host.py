@@ -444,3 +444,6 @@ def test_sensor_keeps_pending_hit_lists_in_order(ns):
     s._record_pending(entries_of)
     s.reset()
     assert not s._pending and len(asked) == 1 and not s.hitLocs
+    for _ in range(s._PENDING_LIMIT + 1):      # never read, never reset: the old entries are settled, the newest stays pending
+        s._record_pending(entries_of)
+    assert len(s._pending) == 1 and len(s._locs) == 2 * s._PENDING_LIMIT
