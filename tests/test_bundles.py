@@ -208,6 +208,30 @@ def test_generate_and_trace_keeps_the_other_paths(ns):
 
 
 @pytest.mark.gpu
+def test_generate_and_trace_matches_the_oracle(ns):
+    """The launch that generates and traces, against the CPU oracle given the rays the sampling kernel makes for the
+    same key: positions, directions and the sensor's hit list within the 1e-5 of the parity contract."""
+    from raytracetorch_amd.rays.ray import SampledRays
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    scene = ns.SequentialScene([lens, sensor])
+    b, _, _ = _device_bundle(ns, "disk_unposed")
+    b.transform.trans.data[2] = -30.0
+    src = b.sample(30001, offset=0, seed=11)
+    src._pos                                         # the sample itself, for the oracle
+    fresh = b.sample(30001, offset=0, seed=11)
+    assert type(fresh) is SampledRays
+    out = scene.simulate(fresh)
+    ref = O.trace_sequential(scene._program(), src.pos.cpu(), src.dir.cpu(), src.intensity.cpu())
+    assert rel_err(out.pos.cpu().numpy(), ref["pos"].numpy()) < 1e-5
+    assert rel_err(out.dir.cpu().numpy(), ref["dir"].numpy()) < 1e-5
+    assert torch.equal(out.intensity.cpu() > 0, ref["intensity"] > 0)
+    locs, w, ids = sensor.getHitsTensors()
+    _, mask, hl, _ = ref["sensor"][0]
+    assert locs.shape[0] == int(mask.sum()) and rel_err(locs.cpu().numpy(), hl[mask].numpy()) < 1e-5
+    assert (ids == b.ray_id).all()
+
+
+@pytest.mark.gpu
 def test_device_gaussian_beam_is_normal(ns):
     """The Box-Muller normals of the device sampler against the normal CDF (Kolmogorov-Smirnov) and for
     independence of x and y."""
