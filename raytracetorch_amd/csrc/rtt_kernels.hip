@@ -107,23 +107,16 @@ DI float sqrt_(float x) { return kStrict ? sqrtf(x) : __builtin_amdgcn_sqrtf(x);
 DI f2 sqrt_(f2 x) { return f2{sqrt_(x.x), sqrt_(x.y)}; }
 DI float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
 DI f2 rsq_(f2 x) { return f2{rsq_(x.x), rsq_(x.y)}; }
-// sqrt for the discriminant: x * rsqrt(x) (hardware reciprocal square root, <= 1 ulp) plus one Newton step on the
-// exact residual fma(-s, s, x); the result is within 0.5 ulp (+ 2^-24 relative) of the true root, i.e. correctly
-// rounded except for rare near-ties, at a third of the instructions of the full IEEE expansion and with one
-// transcendental instruction per root (the correction needs the reciprocal root anyway).
+// sqrt for the discriminant: hardware sqrt (<= 1 ulp) plus one Newton step on the exact residual
+// fma(-s, s, x); the result is within 0.5 ulp (+ 2^-24 relative) of the true root, i.e. correctly
+// rounded except for rare near-ties, at a third of the instructions of the full IEEE expansion.
 DI float sqrt_disc(float x) {
   if (kStrict) return sqrtf(x);
-  const float r = __builtin_amdgcn_rsqf(fmaxf(x, 1e-37f));
-  const float s = x * r;
-  return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * r, s);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float h = 0.5f * __builtin_amdgcn_rsqf(fmaxf(x, 1e-37f));
+  return __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
 }
-DI f2 sqrt_disc(f2 x) {
-  if (kStrict) return f2{sqrtf(x.x), sqrtf(x.y)};
-  // one reciprocal square root per component, the products and the correction step on packed lanes
-  const f2 r = f2{__builtin_amdgcn_rsqf(fmaxf(x.x, 1e-37f)), __builtin_amdgcn_rsqf(fmaxf(x.y, 1e-37f))};
-  const f2 s = x * r;
-  return __builtin_elementwise_fma(__builtin_elementwise_fma(-s, s, x), 0.5f * r, s);
-}
+DI f2 sqrt_disc(f2 x) { return f2{sqrt_disc(x.x), sqrt_disc(x.y)}; }
 DI float quot(float a, float b) { return kStrict ? a / b : a * rcp_(b); }
 DI f2 quot(f2 a, f2 b) { return kStrict ? a / b : a * rcp_(b); }
 // a / b from the hardware reciprocal plus one correction step on the exact residual fma(-b, q, a): within
@@ -785,14 +778,9 @@ DI V3<T> surface_normal(const RV& S, V3<T> h) {
       const T nx = C::sk(S.r) == RTT_SURF_QUADRIC ? two_c * h.x : zero;
       const T ny = two_c * h.y;
       const T nz = two_c1k * h.z - 2.0f;
-      const T n2 = nx * nx + ny * ny + nz * nz;
-      if (kStrict) {
-        const T len = sqrt_(n2) + 1e-8f;
-        return {-div_ieee(nx, len), -div_ieee(ny, len), -div_ieee(nz, len)};
-      }
-      // -v / (|v| + 1e-8) with one reciprocal square root: |v| is about 2 (v_z = 2 c (1+k) z - 2), where the 1e-8 is
-      // below half a unit in the last place; the clamp keeps the reference's 0 for v = 0 (0 * 1e15, not 0 * inf)
-      const T r = -rsq_(max_(n2, splat<T>(1e-30f)));
+      const T len = sqrt_(nx * nx + ny * ny + nz * nz) + 1e-8f;
+      if (kStrict) return {-div_ieee(nx, len), -div_ieee(ny, len), -div_ieee(nz, len)};
+      const T r = -rcp_(len);
       return {nx * r, ny * r, nz * r};
     }
     default: {  // cone, primitives.py:468-497
