@@ -161,22 +161,39 @@ def device_bundle(n, device, seed, offset=0, ns=None):
     return pos, d
 
 
-def measured_traffic(workload, n):
-    """(HBM bytes per launch, note) from the committed rocprofv3 PMC passes of this same command.  The figure is
-    attached only when the profile was taken with the very library that is loaded now (SHA-256 recorded in the
-    file) and with the same ray count; otherwise (None, reason)."""
+def profile_mode(workload):
+    """What, beside workload, ray count and library, decides which kernels a step launches: the backward mode of the
+    spot workload (reverse-mode or forward-mode kernels).  A counter profile describes one mode only."""
+    return os.environ.get("RTT_BACKWARD", "adjoint") if workload == "spot" else None
+
+
+def matching_profiles(workload, n):
+    """Committed traffic files of this workload, newest round first, each with the reason it does not describe the run
+    that is being timed (None when it does): other ray count, other build of the library, other backward mode."""
     import glob
-    sha = lib_sha16()
-    reason = f"no committed profile of workload {workload}"
+    sha, mode = lib_sha16(), profile_mode(workload)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"traffic_{workload}.json")), reverse=True):
         d = json.load(open(f))
+        name = os.path.relpath(f, ROOT)
+        why = None
         if d.get("rays_per_gpu") != n:
-            reason = f"{os.path.relpath(f, ROOT)} was taken at {d.get('rays_per_gpu')} rays"
-            continue
-        if d.get("lib_sha16") != sha:
-            reason = f"{os.path.relpath(f, ROOT)} was taken with another build of the library ({d.get('lib_sha16')} != {sha})"
-            continue
-        return d["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+            why = f"{name} was taken at {d.get('rays_per_gpu')} rays"
+        elif d.get("lib_sha16") != sha:
+            why = f"{name} was taken with another build of the library ({d.get('lib_sha16')} != {sha})"
+        elif (d.get("backward_mode") or ("adjoint" if workload == "spot" else None)) != mode:
+            why = f"{name} was taken with RTT_BACKWARD={d.get('backward_mode') or 'adjoint'}, this run uses {mode}"
+        yield name, d, why
+
+
+def measured_traffic(workload, n):
+    """(HBM bytes per step, note) from the committed rocprofv3 PMC passes of this same command.  The figure is
+    attached only when the profile was taken with the very library that is loaded now (SHA-256 recorded in the
+    file), with the same ray count and in the same backward mode; otherwise (None, reason)."""
+    reason = f"no committed profile of workload {workload}"
+    for name, d, why in matching_profiles(workload, n):
+        if why is None:
+            return d["traffic_bytes_per_launch"], name
+        reason = why
     return None, reason
 
 
@@ -185,17 +202,14 @@ def measured_issue(workload, n):
     traffic): share of the kernel's cycles in which the vector / scalar unit of a SIMD issues, and vector instructions
     per ray.  For the kernels that are bound by instruction issue and latency rather than by HBM this, not the HBM
     fraction, says how close they run to their bound.  None when there is no profile of the loaded build."""
-    import glob
-    sha = lib_sha16()
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"traffic_{workload}.json")), reverse=True):
-        d = json.load(open(f))
-        if d.get("rays_per_gpu") != n or d.get("lib_sha16") != sha or not d.get("kernels"):
+    for source, d, why in matching_profiles(workload, n):
+        if why is not None or not d.get("kernels"):
             continue
         name, k = max(d["kernels"].items(), key=lambda kv: kv[1].get("avg_us", 0.0) * kv[1].get("launches_per_step", 1.0))
         if "valu_busy" not in k:
             return None
         return {"kernel": name[:48], "kernel_us": k.get("avg_us"), "valu_busy": k.get("valu_busy"), "salu_busy": k.get("salu_busy"),
-                "valu_insts_per_ray": k.get("valu_insts_per_ray"), "source": os.path.relpath(f, ROOT)}
+                "valu_insts_per_ray": k.get("valu_insts_per_ray"), "source": source}
     return None
 
 
@@ -487,10 +501,11 @@ def main():
         with torch.cuda.graph(graph):
             step()
         step = graph.replay
-    for _ in range(a.warmup):
+    for _ in range(a.warmup - 1):
         step()
     # Launch-bound sizes (a step of a few tens of microseconds): two event records per step would cost as much as the
-    # step, so one pair brackets all K steps and only the mean is reported.
+    # step, so one pair brackets all K steps and only the mean is reported.  The last warm-up step is the one that is
+    # clocked for this decision, so the command dispatches exactly warmup + steps launches (with --warmup 0, one more).
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step()

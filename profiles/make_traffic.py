@@ -1,5 +1,7 @@
 """Turn the rocprofv3 passes of profiles/run_pmc.sh into the traffic file bench.py attaches to its roofline:
-    python profiles/make_traffic.py gpurun_out/prof_<tag> <workload> <rays per GPU> <out.json>
+    python profiles/make_traffic.py gpurun_out/prof_<tag> <workload> <rays per GPU> <out.json> <steps>
+<steps> = the steps the profiled command executed, warm-up included (run_pmc.sh: --steps 5 --warmup 2 -> 7); the
+dispatches of a kernel divided by it are its launches per step.
 HBM bytes per step = sum over the workload's own kernels of (FETCH_SIZE x 2 + WRITE_SIZE) KB per dispatch x dispatches
 per step (FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950; WRITE_SIZE is exact), from separate --pmc passes.
 The file records the SHA-256 of the kernel library the passes ran with; bench.py ignores it for any other build."""
@@ -12,6 +14,9 @@ import sys
 from collections import defaultdict
 
 root, workload, rays, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+if len(sys.argv) < 6 and not os.environ.get("RTT_PROFILE_STEPS"):
+    raise SystemExit("make_traffic.py: give the number of steps the profiled command ran (steps + warm-up) as the fifth argument")
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else int(os.environ["RTT_PROFILE_STEPS"])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.environ.get("RTT_HIP_LIB") or os.path.join(ROOT, "raytracetorch_amd", "csrc", "librtt_hip.so")
 OWN = ("k_trace_seq", "k_simulate_nearest", "k_ray_cast", "k_spot_moments", "k_sum_partials", "k_sample_bundle")
@@ -37,9 +42,8 @@ for f in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True
         k = short(row["Name"])
         if k and not k.startswith("k_sample_bundle"):
             stats[k] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3}
-# the kernel launched once per step sets the step count; a workload whose every kernel is launched several times per
-# step (the stages of the bounce loop) states its step count in RTT_PROFILE_STEPS
-steps = int(os.environ.get("RTT_PROFILE_STEPS", "0")) or (min(v["calls"] for v in stats.values()) if stats else 1)
+# The step count is given, never inferred from the dispatch counts: a command may dispatch a kernel outside its steps,
+# and the stages of the bounce loop launch every kernel several times per step.
 kernels, total = {}, 0.0
 for k, cs in counters.items():
     mean = {c: sum(v) / len(v) for c, v in cs.items()}
@@ -58,12 +62,13 @@ for k, cs in counters.items():
             entry["waves"] = mean["SQ_WAVES"]
     kernels[k] = entry
     total += bytes_launch * per_step
-doc = {"workload": workload, "rays_per_gpu": rays, "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
+doc = {"workload": workload, "rays_per_gpu": rays, "steps_profiled": steps,
+       "backward_mode": os.environ.get("RTT_BACKWARD", "adjoint") if workload == "spot" else None, "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
        "source": f"rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --workload {workload}` (profiles/run_pmc.sh), "
                  f"means per dispatch",
        "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2; WRITE_SIZE exact",
        "traffic_bytes_per_launch": int(round(total)), "kernels": kernels,
-       "note": "traffic_bytes_per_launch sums the HBM bytes of every kernel of one step; valu_busy / salu_busy = issue cycles of the "
+       "note": "traffic_bytes_per_launch sums the HBM bytes of every kernel of one step (hbm_bytes_per_launch x launches_per_step); valu_busy / salu_busy = issue cycles of the "
                "vector / scalar unit per SIMD over the kernel's cycles"}
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else "...") for k, v in doc.items()}))

@@ -7,7 +7,8 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+STEPS=5; WARMUP=2   # make_traffic.py divides dispatch counts by STEPS + WARMUP
+ARGS="--steps $STEPS --warmup $WARMUP --no-cpu-baseline $*"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $ARGS > $out/trace.log 2>&1 || exit 1
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS" \

@@ -159,6 +159,9 @@ class DeviceProgram:
                 return dp
             dp = cls._upload(np.asarray(prog), device, index, tag)
             facts[("device copy", index, tag)] = dp
+            # the device copy is found again by the identity of `prog`, not by its bytes: from here on the records
+            # are read-only, so that an edit in place raises instead of tracing the stale copy (edit a `.copy()`)
+            prog.flags.writeable = False
             return dp
         return cls._upload(prog, device, index, tag)
 

@@ -3030,16 +3030,29 @@ int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, int block = 
   return (int64_t)block * 4 * ((int64_t)n_acc + (int64_t)n_surf * kAdjState * rays_per_lane);
 }
 
+constexpr int kMaxDevices = 64;
+
+// Dynamic LDS above 64 KB has to be granted per kernel and per device (each device holds its own copy of the code
+// object): done once for the device that is current, remembered per device and instantiation.
+template <class T, int BS>
+int grant_adjoint_lds() {
+  static std::atomic<bool> granted[kMaxDevices];
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return RTT_E_LAUNCH;
+  if (granted[dev].load(std::memory_order_acquire)) return RTT_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kLdsBytes) != hipSuccess)
+    return RTT_E_LAUNCH;
+  granted[dev].store(true, std::memory_order_release);
+  return RTT_OK;
+}
+
 template <class T, int BS>
 int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
                    int vec, int64_t lds, int blocks, hipStream_t st) {
-  static bool raised = false;  // dynamic LDS above 64 KB has to be granted once per kernel
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsBytes) != hipSuccess)
-      return RTT_E_LAUNCH;
-    raised = true;
-  }
+  const int rc = grant_adjoint_lds<T, BS>();
+  if (rc != RTT_OK) return rc;
+  if (blocks == 0) return RTT_OK;  // a call without rays only prepares the device
   hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am, a, vec);
   return launch_status();
 }
@@ -3077,12 +3090,8 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   const int bs = g_adjoint_block;
   if (adjoint_lds_bytes(n_surf, n_acc, lanes) > kLdsBytes) return RTT_E_SIZE;  // (the budget is stated for 256 threads)
   const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes, bs);
-  if (n == 0) {
-    if (n_acc > 0 && hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) != hipSuccess) return RTT_E_LAUNCH;
-    return RTT_OK;
-  }
   const int64_t tile = (int64_t)bs * lanes;
-  int64_t blocks = (n + tile - 1) / tile;
+  int64_t blocks = (n + tile - 1) / tile;  // none for a call without rays, which still prepares the current device
   if (blocks > kAdjMaxBlocks) blocks = kAdjMaxBlocks;
   if (n_acc > 0 && blocks > partial_rows) return RTT_E_SIZE;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
@@ -3099,6 +3108,7 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
     rc = lanes == 2 ? launch_adjoint<f2, 256>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
                     : launch_adjoint<float, 256>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
   if (rc != RTT_OK || n_acc == 0) return rc;
+  if (n == 0) return hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
   hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, (int64_t)n_acc, (int64_t)1, slot_adj);
   return launch_status();
 }
@@ -3111,7 +3121,6 @@ static __device__ __align__(256) double scratch[(size_t)kAdjMaxBlocks * kAdjMaxA
 
 namespace {
 
-constexpr int kMaxDevices = 64;
 std::atomic<double*> g_scratch_ptr[kMaxDevices];
 
 // Address of `scratch` on the current device, looked up once per device (each GPU holds its own copy at its own address).
@@ -3385,6 +3394,9 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
     if (prog_host[s].phys_kind == RTT_PHYS_FRESNEL) return RTT_E_KIND;  // its draws are keyed by the place in the launch
   if (any_sensor && (!hit_count || (hit_capacity > 0 && (!hit_list || !hit_keys)))) return RTT_E_NULL;
   if (n == 0) return RTT_OK;
+  if (max_bounces == 0)  // no stage would run: the single launch copies the rays through and writes zero bounce counts
+    return rtt_simulate_nearest_f32(pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n, prog_dev, prog_host,
+                                    n_surf, 0, bounces, hit_list, hit_keys, hit_count, hit_capacity, hit_parts, stream);
   const hipStream_t sm = (hipStream_t)stream;
   // bounces per stage: while (nearly) every ray still moves a stage boundary only costs; then rays drop out quickly,
   // later the few that are left stay for long.  Measured on the 32-surface scene at 4 Mi rays x 100 bounces: 3.3 ms with

@@ -35,11 +35,13 @@ class Sensor(Element):
         d["_dense"] = []  # (hit planes [3,N], w [N], mask [N] uint8, id [N]) per visit, not yet compacted
         d["_dense_bytes"] = 0
         d["_pending"] = []  # hit lists of fused bounce loops nobody has waited for yet; always older than `_dense`
+        d["_pending_bytes"] = 0  # device memory those launches keep alive (hit lists and their input planes)
 
     # A dense record holds 17 bytes per *ray*, the reference's list entry 17 bytes per *hit*: a sensor that is neither
     # read nor reset for many visits (a long stepping loop) compacts its pending records once they pass this size.
     _DENSE_LIMIT = 4 << 30
-    _PENDING_LIMIT = 8
+    _PENDING_LIMIT = 64          # entries
+    _PENDING_BYTES = 1 << 30     # device memory the pending entries may keep alive
 
     def _record_dense(self, hit_planes, w, mask, ids):
         self._dense.append((hit_planes, w, mask, ids))
@@ -57,19 +59,24 @@ class Sensor(Element):
         if d["_dense_bytes"] > self._DENSE_LIMIT and len(d["_dense"]) > 1:
             self._flush()
 
-    def _record_pending(self, entries_of):
+    def _record_pending(self, entries_of, nbytes=0):
         """The crossings of a launch that is still running: `entries_of(self)` gives this sensor's list entries
-        [(locs, w, ids)] once somebody reads them (the first call waits for the device)."""
+        [(locs, w, ids)] once somebody reads them (the first call waits for the device).  `nbytes` = the device memory
+        the entry keeps alive until then (the launch's hit list and its input planes)."""
         if self._dense:
             self._flush()   # keeps the order of the entries: what is pending is older than what is dense
-        if len(self._pending) >= self._PENDING_LIMIT:
-            # a pending entry keeps the launch's whole hit list and its input planes alive: a sensor that is neither read
-            # nor reset over many launches settles the old ones (which waits for them) before it takes another
+        d = self.__dict__
+        if d["_pending"] and (len(d["_pending"]) >= self._PENDING_LIMIT or d["_pending_bytes"] + nbytes > self._PENDING_BYTES):
+            # a sensor that is neither read nor reset over many launches settles the old entries (which waits for
+            # them and frees what they held) before it takes another: the memory held is bounded in bytes, whatever
+            # the size of the bundles
             self._resolve_pending()
-        self._pending.append(entries_of)
+        d["_pending"].append(entries_of)
+        d["_pending_bytes"] += int(nbytes)
 
     def _resolve_pending(self):
         pending, self.__dict__["_pending"] = self._pending, []
+        self.__dict__["_pending_bytes"] = 0
         for entries_of in pending:
             for locs, w, ids in entries_of(self):
                 self._locs.append(locs)

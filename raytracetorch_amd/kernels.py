@@ -385,6 +385,13 @@ class PendingHits:
         self.lists = lists
         self.result = None
 
+    def nbytes(self) -> int:
+        """Device memory this entry keeps alive until it is resolved or dropped: the lists and the input planes."""
+        if self.lists is None:
+            return 0
+        held = [t for t in self.lists[:3] if t is not None] + [t for t in self.src if t is not None]
+        return sum(t.numel() * t.element_size() for t in held)
+
     def resolve(self):
         if self.result is None:
             hit, keys, count, parts = self.lists

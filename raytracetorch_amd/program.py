@@ -127,8 +127,9 @@ def sag_f32(c, tz, r) -> np.float32:
 class Program(np.ndarray):
     """The packed records of a scene, as `compile_elements` returns them: a structured array that also carries facts
     derived from it once (`facts`: number of sensor slots, presence of a stochastic functor, device copies), so that a
-    repeated launch of an unchanged program does not derive them again.  Slices and copies are plain arrays of records
-    without facts."""
+    repeated launch of an unchanged program does not derive them again.  Slices and copies start without facts.  Once
+    a device copy has been derived the records are made read-only (`flags.writeable = False`): a changed program is a
+    new `Program` (`prog.copy()`), never an edit in place, which would leave the facts stale."""
 
     def __array_finalize__(self, obj):
         self.facts = None

@@ -234,8 +234,9 @@ class Scene(nn.Module):
             if not split:
                 split["entries"] = self._split_sensor_hits(plan, ids, *hits.resolve())
             return [e[1:] for e in split["entries"] if e[0] is sensor]
+        held = hits.nbytes()   # the hit list and the input planes stay allocated until the entry is read or dropped
         for el in {id(el): el for _, el, fuzzy in plan if fuzzy is None}.values():
-            el._record_pending(entries_of)
+            el._record_pending(entries_of, held)
 
     def _has_fuzzy(self) -> bool:
         return any(hasattr(fn, "block_function") for el in self.elements for fn in el.surface_functions)

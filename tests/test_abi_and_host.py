@@ -447,3 +447,11 @@ def test_sensor_keeps_pending_hit_lists_in_order(ns):
     for _ in range(s._PENDING_LIMIT + 1):      # never read, never reset: the old entries are settled, the newest stays pending
         s._record_pending(entries_of)
     assert len(s._pending) == 1 and len(s._locs) == 2 * s._PENDING_LIMIT
+    # the entries are bounded by the device memory they keep alive, not only by their number: three launches that hold
+    # 0.4 GiB each pass the 1 GiB limit with the third, which settles the first two
+    s.reset()
+    for _ in range(3):
+        s._record_pending(entries_of, nbytes=int(0.4 * 2 ** 30))
+    assert len(s._pending) == 1 and len(s._locs) == 4 and s._pending_bytes == int(0.4 * 2 ** 30)
+    s._record_pending(entries_of, nbytes=2 ** 31)     # one entry larger than the limit is still taken (after settling the rest)
+    assert len(s._pending) == 1 and len(s._locs) == 6

@@ -160,7 +160,8 @@ def test_naive_ray_cast_and_step(ns):
     rays = rays_from_golden(ns, g, device=DEV)
     tm = cpu(torch.cat([el.intersectTest(rays) for el in scene.elements], dim=1))
     assert pattern_mismatch(tm, g["t_matrix"]) == 0
-    assert rel_err(tm.reshape(-1), g["t_matrix"].reshape(-1)) < PARITY_TOL
+    # a benchmark configuration: purely relative bounds (floor 0), no tie-break
+    assert rel_err(tm.reshape(-1), g["t_matrix"].reshape(-1), floor=0.0) < PARITY_TOL
     hit, el_ids, sf_ids = scene.ray_cast(rays)
     hit, el_ids, sf_ids = cpu(hit), cpu(el_ids), cpu(sf_ids)
     assert np.array_equal(hit, g["hit_mask"])
@@ -175,7 +176,7 @@ def test_naive_ray_cast_and_step(ns):
     r = scene.rays
     ok = ~tie
     for f, got in (("pos", r.pos), ("dir", r.dir), ("intensity", r.intensity)):
-        assert rel_err(cpu(got)[ok], g[f"step1_{f}"][ok]) < PARITY_TOL, f
+        assert rel_err(cpu(got)[ok], g[f"step1_{f}"][ok], floor=0.0) < PARITY_TOL, f
     sensor = scene.elements[-1]
     if "sensor_locs" in g:
         locs, w, _ = sensor.getHitsTensors()

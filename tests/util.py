@@ -12,26 +12,33 @@ def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
-def ray_err(a, b):
-    """Per-entry relative deviation of `a` from `b`; NaN where either side is not finite.
+def ray_err(a, b, floor=1.0):
+    """Per-entry deviation of `a` from `b`, relative to the magnitude of `b` but to no less than `floor`; NaN where
+    either side is not finite.
 
-    [N] arrays: |a-b| / max(1, |b|).  [N,3] arrays (positions, directions, normals): per ray
-    max_c |a-b| / max(1, ||b||_2), i.e. relative to the length of the reference vector."""
+    [N] arrays: |a-b| / max(floor, |b|).  [N,3] arrays (positions, directions, normals): per ray
+    max_c |a-b| / max(floor, ||b||_2), i.e. relative to the length of the reference vector.
+
+    With the default floor of 1 the measure is relative for magnitudes above 1 and ABSOLUTE below: it suits
+    quantities whose natural scale is the scene (a hit point in a sensor's own frame near the axis, a distance that
+    may be tiny), and it is what the non-benchmark goldens are held to.  `floor=0` is the purely relative measure the
+    benchmark configurations are held to (entries whose reference is exactly zero must then be exactly zero)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     if a.shape != b.shape:
         raise AssertionError(f"shape mismatch {a.shape} vs {b.shape}")
-    with np.errstate(invalid="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore"):
         if a.ndim == 2 and a.shape[1] == 3:
             fin = np.isfinite(a).all(1) & np.isfinite(b).all(1)
-            e = np.abs(a - b).max(1) / np.maximum(1.0, np.linalg.norm(b, axis=1))
+            num, den = np.abs(a - b).max(1), np.maximum(floor, np.linalg.norm(b, axis=1))
         else:
             fin = np.isfinite(a) & np.isfinite(b)
-            e = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+            num, den = np.abs(a - b), np.maximum(floor, np.abs(b))
+        e = np.where(den > 0, num / np.where(den > 0, den, 1.0), np.where(num > 0, np.inf, 0.0))
     return np.where(fin, e, np.nan)
 
 
-def rel_err(a, b):
-    e = ray_err(a, b)
+def rel_err(a, b, floor=1.0):
+    e = ray_err(a, b, floor)
     return 0.0 if e.size == 0 or np.isnan(e).all() else float(np.nanmax(e))
 
 
@@ -54,8 +61,20 @@ def is_hard_case(name):
     return name in HARD_CASES
 
 
+# Quantities that live in a surface's own frame: their magnitude near the axis is arbitrarily small while their
+# rounding error is that of the global coordinates they were computed from, so a purely relative bound has no
+# meaning for them (the reference's float32 misses its own float64 by more); they keep the floor of 1.
+LOCAL_FRAME = ("hit_local", "sensor locs", "sensor hit_local")
+
+
 def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what="", hard=False):
     """`got` agrees with the reference's float32 result `ref` within `tol` on every ray.
+
+    `hard` (the benchmark configurations): the bound is purely RELATIVE, |got - ref| <= tol * |ref| per ray (vectors:
+    largest component deviation over the length of the reference vector), for positions, directions, normals,
+    distances and intensities; hit points in a surface's own frame keep the floor of `ray_err`.  No float64
+    evaluation is consulted.  Otherwise the deviation is measured with `ray_err`'s floor of 1 (absolute below unit
+    magnitude), and:
 
     Two correct float32 evaluations can differ by more than that on ill-conditioned rays: the
     reference's torch-CPU sqrt (MKL VML) is not correctly rounded while gfx950's is, and one ulp
@@ -64,7 +83,8 @@ def assert_parity(got, ref, truth=None, tol=PARITY_TOL, what="", hard=False):
     case is accepted if `got` is no further from `truth` than twice the reference's own deviation
     from it, both at the worst ray and at the 99th percentile; the case is then entered in TIE_BREAKS.
     `hard` ignores `truth`: the plain tolerance decides."""
-    e = ray_err(got, ref)
+    floor = 0.0 if hard and not any(k in what for k in LOCAL_FRAME) else 1.0
+    e = ray_err(got, ref, floor)
     if e.size == 0 or np.isnan(e).all():
         return
     worst = float(np.nanmax(e))
