@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--tune-reduce-blocks", type=int, default=0, help="override the grid of the reducing kernels (experiment)")
     ap.add_argument("--tune-cull", type=int, default=-1, help="0: nearest-hit kernels test every surface (experiment)")
     ap.add_argument("--tune-adjoint-lane", type=int, default=0, help="rays per lane of the reverse-mode backward: 1, 2, 0 = automatic")
-    ap.add_argument("--tune-adjoint-block", type=int, default=0, help="threads per block of the reverse-mode backward: 128 or 256")
+    ap.add_argument("--tune-adjoint-state", type=int, default=-1, help="1: the reverse-mode backward keeps its states in LDS also for short programs")
     return ap.parse_args()
 
 
@@ -471,8 +471,8 @@ def main():
         _native.check(_native.lib().rtt_tune(3, a.tune_cull), "rtt_tune")
     if a.tune_adjoint_lane:
         _native.check(_native.lib().rtt_tune(6, a.tune_adjoint_lane), "rtt_tune")
-    if a.tune_adjoint_block:
-        _native.check(_native.lib().rtt_tune(7, a.tune_adjoint_block), "rtt_tune")
+    if a.tune_adjoint_state >= 0:
+        _native.check(_native.lib().rtt_tune(7, a.tune_adjoint_state), "rtt_tune")
 
     if a.workload != "singlet":
         return other_workload(a, ns, scenes, dev, rank, world, dist)

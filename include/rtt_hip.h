@@ -421,7 +421,8 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048;
  * key 6: rays per lane of rtt_trace_seq_adjoint_f32: 0 (default) two when the LDS need allows two blocks per compute
  * unit, else one; 1 or 2 force the choice;
- * key 7: threads per block of rtt_trace_seq_adjoint_f32, 256 (default) or 128;
+ * key 7: where rtt_trace_seq_adjoint_f32 keeps the per-surface ray states and the slot sums: 0 (default) in registers
+ * when the program has at most 4 surfaces and at most 64 slot sums are asked for, else in LDS; 1 always in LDS;
  * key 8: threads per block of rtt_spot_moments_f32 on 16-byte aligned records, 1024 (default) or 256.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);

@@ -68,11 +68,50 @@ struct SlotSink {
   }
 };
 
+// Sum of a float over the 64 lanes of the wavefront with data-parallel-primitive adds (no LDS): lanes exchange within
+// quads, then within rows of 16 (mirrors), then lane 15 / 31 of a row is broadcast into the following rows; lane 63
+// ends up with the total, which is returned to every lane through a scalar register.
+template <int CTRL, int ROW_MASK>
+DI float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+DI float wave_total(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane of a row holds the row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// The sink of the register-resident sweep: no per-lane accumulators at all.  A contribution is summed over the
+// wavefront at once (float32 over 64 or 128 values) and added, in float64, to accumulator a, which lives in lane a of
+// one register pair of the wavefront: up to 64 accumulators cost two registers, and the index a may be any
+// wave-uniform run-time value.
+template <class T>
+struct WaveSink {
+  double* acc;    // the wavefront's accumulator register (lane a = accumulator a)
+  uint32_t mask;  // wanted slots of the surface (wave-uniform)
+  int base;
+  typename LaneOf<T>::M on;
+  bool all_on;
+  DI bool wants(int slot) const { return (mask >> slot) & 1u; }
+  DI bool wants_any(uint32_t slots) const { return (mask & slots) != 0u; }
+  DI void add(int slot, T v) const {
+    if (!wants(slot)) return;  // scalar branch
+    const int a = base + __builtin_popcount(mask & ((1u << slot) - 1u));
+    const float x = wave_total(all_on ? hsum(v) : hsum(sel(on, v, splat<T>(0.0f))));
+    if ((int)(threadIdx.x & 63u) == a) *acc += (double)x;
+  }
+};
+
 constexpr uint32_t kSlotsRs = 0x1ffu, kSlotsRj = 0x1ffu << 12;
 
 // dR[3i + j] += a_i b_j for the rotation whose slots start at `first`
-template <class T>
-DI void sink_outer(const SlotSink<T>& sk, int first, V3<T> a, V3<T> b) {
+template <class SK, class T>
+DI void sink_outer(const SK& sk, int first, V3<T> a, V3<T> b) {
   sk.add(first + 0, a.x * b.x); sk.add(first + 1, a.x * b.y); sk.add(first + 2, a.x * b.z);
   sk.add(first + 3, a.y * b.x); sk.add(first + 4, a.y * b.y); sk.add(first + 5, a.y * b.z);
   sk.add(first + 6, a.z * b.x); sk.add(first + 7, a.z * b.y); sk.add(first + 8, a.z * b.z);
@@ -80,9 +119,9 @@ DI void sink_outer(const SlotSink<T>& sk, int first, V3<T> a, V3<T> b) {
 
 // Adjoint of SurfaceFunction.forward: given g = adjoint of new_dir, returns the adjoints of the incoming direction
 // (db) and of the normal (nb), adds to the adjoint of hit_local (hlb) and hands the slot adjoints to the sink.
-template <class C, class T>
+template <class C, class T, class SK>
 DI void physics_adjoint(const RecF& S, V3<T> hl, V3<T> d, V3<T> n, V3<T> g, V3<T>& db, V3<T>& nb, V3<T>& hlb,
-                        uint64_t ridx, const SlotSink<T>& sk) {
+                        uint64_t ridx, const SK& sk) {
   const T zero = splat<T>(0.0f), one = splat<T>(1.0f);
   db = {zero, zero, zero};
   nb = {zero, zero, zero};
@@ -176,8 +215,8 @@ DI void physics_adjoint(const RecF& S, V3<T> hl, V3<T> d, V3<T> n, V3<T> g, V3<T
 }
 
 // Adjoint of _getNormal in the surface frame: nlb = adjoint of the local normal nl at the local hit point h.
-template <class C, class T>
-DI void normal_adjoint(const RecF& S, V3<T> h, V3<T> nl, V3<T> nlb, V3<T>& hb, const SlotSink<T>& sk) {
+template <class C, class T, class SK>
+DI void normal_adjoint(const RecF& S, V3<T> h, V3<T> nl, V3<T> nlb, V3<T>& hb, const SK& sk) {
   const T zero = splat<T>(0.0f);
   switch (C::sk(S.r)) {
     case RTT_SURF_PLANE:
@@ -233,8 +272,8 @@ DI void normal_adjoint(const RecF& S, V3<T> h, V3<T> nl, V3<T> nlb, V3<T>& hb, c
 // Adjoint of the path length: t solves A t^2 + B t + C = 0 (coefficients of the surface kind in o = pl, d = dl), so
 //   dt = -(go . d(o) + gd . d(d) + g0 d(geom[i0]) + g1 d(geom[i1])) / den
 // with the same coefficient vectors as the tangent kernels; tb is the adjoint of t.
-template <class C, class T>
-DI void root_adjoint(const RecF& S, V3<T> o, V3<T> d, T t, V3<T> h, T tb, V3<T>& ob, V3<T>& db, const SlotSink<T>& sk) {
+template <class C, class T, class SK>
+DI void root_adjoint(const RecF& S, V3<T> o, V3<T> d, T t, V3<T> h, T tb, V3<T>& ob, V3<T>& db, const SK& sk) {
   const T zero = splat<T>(0.0f);
   const T eps = splat<T>(kEps);
   V3<T> go, gd;
@@ -311,9 +350,9 @@ DI void root_adjoint(const RecF& S, V3<T> o, V3<T> d, T t, V3<T> h, T tb, V3<T>&
 // path length the forward sweep kept; pb / db come in as the adjoints of the state behind the surface and leave as
 // the adjoints of the state in front of it.  `ext(hl)` supplies the adjoint that reaches hit_local from outside the
 // trace (a sensor's record), evaluated at the recomputed local hit point.
-template <class C, class T, class M, class Ext>
+template <class C, class T, class M, class SK, class Ext>
 DI void visit_adjoint(const RecF& S, V3<T> p, V3<T> d, T t, M hit, V3<T>& pb, V3<T>& db, uint64_t ridx,
-                      const SlotSink<T>& sk, Ext&& ext) {
+                      const SK& sk, Ext&& ext) {
   const T zero = splat<T>(0.0f);
   const bool shp = C::has_shape(S.r), ids = C::rs_id(S.r), idj = C::rj_id(S.r);
   // ---- the forward quantities again (to_frames, surface_forward) ----
@@ -417,18 +456,94 @@ template <class I> DI f2 ldp_(const float* p, I i, bool vec, int nv, f2*) {
   return f2{p[i], p[i + (nv - 1)]};
 }
 
-// dynamic LDS: float acc[n_acc][BS], then T state[n_surf][kAdjState][BS]; BS threads per block
-// Two wavefronts per SIMD is what the LDS of a four-surface program allows with two rays per lane (three with one).
-template <class T, int BS>
-__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+// f(S), f(S + 1), ..., f(E - 1) and f(S), f(S - 1), ..., f(0) with the index a compile-time constant in every call
+template <int S, int E, class F>
+DI void unrolled(F&& f) {
+  if constexpr (S < E) {
+    f(S);
+    unrolled<S + 1, E>(f);
+  }
+}
+template <int S, class F>
+DI void unrolled_down(F&& f) {
+  if constexpr (S >= 0) {
+    f(S);
+    unrolled_down<S - 1>(f);
+  }
+}
+
+// Where the forward sweep keeps the state in front of every surface.
+// LDS (NS == 0): a lane-private column of dynamic LDS, any number of surfaces, rolled loops.  Per surface either the
+// full state (position, direction, path length: 7 values) or, COMPACT, direction and path length only (4 values) next
+// to the position the ray started from (3 values, once): the position in front of surface s is then made again by
+// walking p <- p + t d over the surfaces before s, the very operations of the forward sweep, so it has the same bits.
+// (Walking back from the end, p - t d, does not: see the head of this file.)  The walk makes the reverse sweep
+// quadratic in the number of surfaces; it is used for short programs, where the smaller footprint buys a third
+// wavefront per SIMD.
+constexpr int kAdjStateCompact = 4, kAdjStart = 3;
+template <class T, int BS, bool COMPACT>
+struct AdjState {
+  static constexpr int kPer = COMPACT ? kAdjStateCompact : kAdjState;
+  T* base;
+  DI AdjState(float* lds_dyn, int n_acc) : base(reinterpret_cast<T*>(lds_dyn + (int64_t)n_acc * BS) + threadIdx.x) {}
+  DI T* of(int s) const { return base + ((int64_t)s * kPer + (COMPACT ? kAdjStart : 0)) * BS; }
+  DI void put_start(V3<T> p) {
+    base[0] = p.x; base[BS] = p.y; base[2 * BS] = p.z;
+  }
+  DI V3<T> get_start() const { return {base[0], base[BS], base[2 * BS]}; }
+  DI void put(int s, V3<T> p, V3<T> d, T t) {
+    T* st = of(s);
+    if (COMPACT) {
+      st[0] = d.x; st[BS] = d.y; st[2 * BS] = d.z; st[3 * BS] = t;
+    } else {
+      st[0] = p.x; st[BS] = p.y; st[2 * BS] = p.z;
+      st[3 * BS] = d.x; st[4 * BS] = d.y; st[5 * BS] = d.z; st[6 * BS] = t;
+    }
+  }
+  DI void get_dir(int s, V3<T>& d, T& t) const {
+    const T* st = of(s);
+    d = {st[0], st[BS], st[2 * BS]};
+    t = st[3 * BS];
+  }
+  DI void get(int s, V3<T>& p, V3<T>& d, T& t) const {
+    const T* st = of(s);
+    p = {st[0], st[BS], st[2 * BS]};
+    d = {st[3 * BS], st[4 * BS], st[5 * BS]};
+    t = st[6 * BS];
+  }
+};
+// Registers (NS > 0): programs of at most NS surfaces; the surface loops are unrolled so that every index below is a
+// compile-time constant and the arrays never leave the register file.
+template <class T, int BS, int NS>
+struct AdjStateReg {
+  V3<T> p[NS], d[NS];
+  T t[NS];
+  DI AdjStateReg(float*, int) {}
+  DI void put(int s, V3<T> pp, V3<T> dd, T tt) { p[s] = pp; d[s] = dd; t[s] = tt; }
+  DI void get(int s, V3<T>& pp, V3<T>& dd, T& tt) const { pp = p[s]; dd = d[s]; tt = t[s]; }
+};
+
+// NS == 0: dynamic LDS = float acc[n_acc][BS], then T state[n_surf][7][BS] or, COMPACT, T start[3][BS] and
+//   T state[n_surf][4][BS]; BS threads per block.  With two rays per lane a four-surface program gets two wavefronts
+//   per SIMD with the full states and three with the compact ones.
+// NS > 0 (n_surf <= NS, n_acc <= 64): state in registers, slot sums in one lane-indexed register pair per wavefront;
+//   no dynamic LDS, occupancy set by the register count alone.
+template <class T, int BS, int NS, bool COMPACT = false>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT ? 3 : 2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                               Ops ops, AccMap am, AdjointIO a, int vec) {
+  static_assert(!(COMPACT && NS > 0), "the compact states are an LDS layout");
   extern __shared__ float lds_dyn[];
+  __shared__ double wave_acc[NS > 0 ? (BS / 64) * 64 : 1];
   constexpr int N = LaneOf<T>::N;
+  constexpr bool REG = NS > 0;
   using M = typename LaneOf<T>::M;
+  using State = typename std::conditional<REG, AdjStateReg<T, BS, REG ? NS : 1>, AdjState<T, BS, COMPACT>>::type;
+  using Sink = typename std::conditional<REG, WaveSink<T>, SlotSink<T>>::type;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   float* acc = lds_dyn + threadIdx.x;
-  T* state = reinterpret_cast<T*>(lds_dyn + (int64_t)a.n_acc * BS) + threadIdx.x;
-  for (int k = 0; k < a.n_acc; ++k) acc[k * BS] = 0.0f;
+  double racc = 0.0;  // REG: accumulator `lane` of this wavefront
+  if (!REG)
+    for (int k = 0; k < a.n_acc; ++k) acc[k * BS] = 0.0f;
   float Gx = 0.0f, Gy = 0.0f, cx = a.cx, cy = a.cy, inv_w = a.inv_w;
   if (a.spot_slot >= 0 && a.spot_mom) {
     const double W = fmax(a.spot_mom[0], 1e-12);  // the reference clamps the weight sum (optim/goals.py:173)
@@ -457,8 +572,12 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4)))
 #pragma unroll
     for (int k = 0; k < N; ++k) bits.b[k] = 0ull;
     T w_spot = splat<T>(0.0f);
+    State state(lds_dyn, a.n_acc);
+    uint64_t any_hit = 0ull, all_hit = 0ull;  // COMPACT: surfaces that some / every ray of the wavefront hit (wave-uniform)
+    if constexpr (COMPACT) state.put_start(r.p);
     // ---- forward sweep: keep the state in front of every surface that is hit ----
-    for (int s = 0; s < n_surf; ++s) {
+    auto forward_visit = [&](const int s) __attribute__((always_inline)) {
+      if (REG && s >= n_surf) return;
       const RecF S{prog[s]};
       Frames<T> f;
       T t_raw;
@@ -467,9 +586,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4)))
   {                                                                                                    \
     hit = test_surface<CFG>(S, r.p, r.d, f, t_raw);                                                    \
     if (__any(any_(hit))) {                                                                            \
-      T* st = state + (int64_t)s * kAdjState * BS;                                                 \
-      st[0] = r.p.x; st[BS] = r.p.y; st[2 * BS] = r.p.z;                                       \
-      st[3 * BS] = r.d.x; st[4 * BS] = r.d.y; st[5 * BS] = r.d.z; st[6 * BS] = t_raw;  \
+      state.put(s, r.p, r.d, t_raw);                                                                   \
+      if (COMPACT) any_hit |= 1ull << s;                                                               \
+      if (COMPACT && __all(all_(hit))) all_hit |= 1ull << s;                                           \
       const Forward<T> fw = surface_forward<CFG>(S, r.p, r.d, f, t_raw);                               \
       V3<T> nd;                                                                                        \
       T im;                                                                                            \
@@ -489,6 +608,11 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4)))
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
       set_bits(bits, s, hit);
+    };
+    if constexpr (REG) {
+      unrolled<0, NS>(forward_visit);
+    } else {
+      for (int s = 0; s < n_surf; ++s) forward_visit(s);
     }
     // ---- adjoint of the final state ----
     T* tag = nullptr;
@@ -507,17 +631,32 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4)))
             ldp_(ad + 2 * a.ld_adj, at, vload, nv ? nv : 1, tag)};
     }
     // ---- reverse sweep ----
-    for (int s = n_surf - 1; s >= 0; --s) {
+    auto reverse_visit = [&](const int s) __attribute__((always_inline)) {
+      if (REG && s >= n_surf) return;
       const M hit = get_bits(bits, s);
-      if (!__any(any_(hit))) continue;
+      if (!__any(any_(hit))) return;
       const RecF S{prog[s]};
-      const T* st = state + (int64_t)s * kAdjState * BS;
-      const V3<T> p = {st[0], st[BS], st[2 * BS]};
-      const V3<T> d = {st[3 * BS], st[4 * BS], st[5 * BS]};
-      const T t = st[6 * BS];
+      V3<T> p, d;
+      T t;
+      if constexpr (COMPACT) {
+        p = state.get_start();
+        for (int j = 0; j < s; ++j) {  // the forward sweep's moves again, on the surfaces in front of s
+          if (!((any_hit >> j) & 1ull)) continue;
+          V3<T> dj;
+          T tj;
+          state.get_dir(j, dj, tj);
+          const V3<T> moved = p + scale(tj, dj);
+          p = ((all_hit >> j) & 1ull) ? moved : sel3(get_bits(bits, j), moved, p);
+        }
+        state.get_dir(s, d, t);
+      } else {
+        state.get(s, p, d, t);
+      }
       const M on = and_(hit, live);
       const bool all_on = __all(all_(on));
-      const SlotSink<T> sk = {acc, BS, am.mask[s], (int)am.base[s], on, all_on};
+      Sink sk;
+      if constexpr (REG) sk = Sink{&racc, am.mask[s], (int)am.base[s], on, all_on};
+      else sk = Sink{acc, BS, am.mask[s], (int)am.base[s], on, all_on};
       const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
       const int slot = S.r.sensor_slot;
       auto ext = [&](V3<T> hl) -> V3<T> {
@@ -547,10 +686,14 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4)))
 #define RTT_CALL(CFG) visit_adjoint<CFG>(S, p, d, t, hit, pb, db, ridx, sk, ext)
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
+    };
+    if constexpr (REG) {
+      unrolled_down<NS - 1>(reverse_visit);
+    } else {
+      for (int s = n_surf - 1; s >= 0; --s) reverse_visit(s);
     }
     if (a.ray_adj && nv) {
       float* ra = a.ray_adj + base;
-      const bool vst = vec != 0 && nv == N && (a.ld_ray % 2 == 0);
       const T comps[6] = {pb.x, pb.y, pb.z, db.x, db.y, db.z};
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -558,20 +701,30 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(2, 4)))
 #pragma unroll
         for (int k = 0; k < N; ++k)
           if (k < nv) plane[idx + k] = comp(comps[c], k);
-        (void)vst;
       }
     }
   }
   // ---- block sums of the slot adjoints, float64 ----
-  __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = wv; k < a.n_acc; k += BS / 64) {
-    const float* col = lds_dyn + (int64_t)k * BS;
-    double v = 0.0;
+  if constexpr (REG) {
+    wave_acc[wv * 64 + lane] = racc;
+    __syncthreads();
+    if (wv == 0 && lane < a.n_acc) {
+      double v = 0.0;
 #pragma unroll
-    for (int j = 0; j < BS / 64; ++j) v += (double)col[lane + 64 * j];
-    v = wave_sum(v);
-    if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;  // read back by k_sum_partials with strides (n_acc, 1)
+      for (int j = 0; j < BS / 64; ++j) v += wave_acc[j * 64 + lane];
+      a.partials[(int64_t)blockIdx.x * a.n_acc + lane] = v;
+    }
+  } else {
+    __syncthreads();
+    for (int k = wv; k < a.n_acc; k += BS / 64) {
+      const float* col = lds_dyn + (int64_t)k * BS;
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS / 64; ++j) v += (double)col[lane + 64 * j];
+      v = wave_sum(v);
+      if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;  // read back by k_sum_partials with strides (n_acc, 1)
+    }
   }
 }
 

@@ -3024,36 +3024,42 @@ constexpr int kAdjMaxBlocks = 2048;          // grid cap of the adjoint kernel =
 constexpr int kAdjMaxAcc = 128;              // accumulators per launch
 constexpr int kLdsBytes = 160 * 1024;        // LDS of a gfx950 compute unit
 int g_adjoint_lane = 0;                      // 0: choose by LDS need, 1: one ray per lane, 2: two rays per lane
-int g_adjoint_block = 256;                   // threads per block of the adjoint kernel (256 or 128)
 
-int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, int block = kBlock) {
-  return (int64_t)block * 4 * ((int64_t)n_acc + (int64_t)n_surf * kAdjState * rays_per_lane);
+int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, bool compact = false) {
+  const int64_t per_ray = compact ? kAdjStart + (int64_t)n_surf * kAdjStateCompact : (int64_t)n_surf * kAdjState;
+  return (int64_t)kBlock * 4 * ((int64_t)n_acc + per_ray * rays_per_lane);
 }
+constexpr int kAdjCompactSurfaces = 6;       // longest program swept with compact states (the walk is quadratic)
 
 constexpr int kMaxDevices = 64;
+constexpr int kAdjRegSurfaces = 4;           // longest program whose per-surface states the sweep keeps in registers
+constexpr int kAdjRegAcc = 64;               // slot sums of that variant: one lane of a register pair each
+int g_adjoint_state = 0;                     // 0: registers when the program and the slot sums fit, 1: always LDS
 
 // Dynamic LDS above 64 KB has to be granted per kernel and per device (each device holds its own copy of the code
 // object): done once for the device that is current, remembered per device and instantiation.
-template <class T, int BS>
+template <class T, int BS, int NS, bool COMPACT>
 int grant_adjoint_lds() {
+  if (NS > 0) return RTT_OK;  // the register variant asks for no dynamic LDS
   static std::atomic<bool> granted[kMaxDevices];
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return RTT_E_LAUNCH;
   if (granted[dev].load(std::memory_order_acquire)) return RTT_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS, NS, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           kLdsBytes) != hipSuccess)
     return RTT_E_LAUNCH;
   granted[dev].store(true, std::memory_order_release);
   return RTT_OK;
 }
 
-template <class T, int BS>
+template <class T, int BS, int NS, bool COMPACT = false>
 int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
                    int vec, int64_t lds, int blocks, hipStream_t st) {
-  const int rc = grant_adjoint_lds<T, BS>();
+  const int rc = grant_adjoint_lds<T, BS, NS, COMPACT>();
   if (rc != RTT_OK) return rc;
   if (blocks == 0) return RTT_OK;  // a call without rays only prepares the device
-  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am, a, vec);
+  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS, NS, COMPACT>), dim3(blocks), dim3(BS), (size_t)(NS > 0 ? 0 : lds), st, io, prog_dev, n_surf,
+                     ops, am, a, vec);
   return launch_status();
 }
 
@@ -3085,12 +3091,18 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   }
   if (n_acc > kAdjMaxAcc) return RTT_E_SIZE;
   if (n_acc > 0 && (!slot_adj || !partials)) return RTT_E_NULL;
+  // short programs with few slot sums keep everything in registers (two rays per lane unless one is forced); the
+  // others keep the per-surface states and per-lane sums in LDS, which then sets rays per lane and occupancy
+  // g_adjoint_state: 0 = compact LDS states for short programs when they buy a third wavefront per SIMD, 1 = full LDS
+  // states always, 2 = registers for programs of at most four surfaces
+  const bool regs = g_adjoint_state == 2 && g_adjoint_lane != 1 && n_surf <= kAdjRegSurfaces && n_acc <= kAdjRegAcc;
+  const bool compact = !regs && g_adjoint_state == 0 && g_adjoint_lane != 1 && n_surf <= kAdjCompactSurfaces &&
+                       adjoint_lds_bytes(n_surf, n_acc, 2, true) <= kLdsBytes / 3 && adjoint_lds_bytes(n_surf, n_acc, 2) > kLdsBytes / 3;
   int lanes = g_adjoint_lane;
-  if (lanes == 0) lanes = adjoint_lds_bytes(n_surf, n_acc, 2) <= kLdsBytes / 2 ? 2 : 1;
-  const int bs = g_adjoint_block;
-  if (adjoint_lds_bytes(n_surf, n_acc, lanes) > kLdsBytes) return RTT_E_SIZE;  // (the budget is stated for 256 threads)
-  const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes, bs);
-  const int64_t tile = (int64_t)bs * lanes;
+  if (lanes == 0) lanes = regs || compact || adjoint_lds_bytes(n_surf, n_acc, 2) <= kLdsBytes / 2 ? 2 : 1;
+  if (!regs && adjoint_lds_bytes(n_surf, n_acc, lanes, compact) > kLdsBytes) return RTT_E_SIZE;
+  const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes, compact);
+  const int64_t tile = (int64_t)kBlock * lanes;
   int64_t blocks = (n + tile - 1) / tile;  // none for a call without rays, which still prepares the current device
   if (blocks > kAdjMaxBlocks) blocks = kAdjMaxBlocks;
   if (n_acc > 0 && blocks > partial_rows) return RTT_E_SIZE;
@@ -3101,12 +3113,13 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) && aligned8(adj_pos) &&
                   aligned8(adj_dir) && aligned8(adj_sens);
-  if (bs == 128)
-    rc = lanes == 2 ? launch_adjoint<f2, 128>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
-                    : launch_adjoint<float, 128>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+  if (regs)
+    rc = launch_adjoint<f2, kBlock, kAdjRegSurfaces>(io, prog_dev, n_surf, ops, am, a, vec, 0, (int)blocks, st);
+  else if (compact)
+    rc = launch_adjoint<f2, kBlock, 0, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
   else
-    rc = lanes == 2 ? launch_adjoint<f2, 256>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
-                    : launch_adjoint<float, 256>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+    rc = lanes == 2 ? launch_adjoint<f2, kBlock, 0>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                    : launch_adjoint<float, kBlock, 0>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
   if (rc != RTT_OK || n_acc == 0) return rc;
   if (n == 0) return hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
   hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, (int64_t)n_acc, (int64_t)1, slot_adj);
@@ -3598,8 +3611,8 @@ int rtt_tune(int key, int value) {
     g_moments_threads = value;
     return RTT_OK;
   }
-  if (key == 7 && (value == 128 || value == 256)) {
-    g_adjoint_block = value;
+  if (key == 7 && value >= 0 && value <= 2) {
+    g_adjoint_state = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;

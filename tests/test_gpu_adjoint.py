@@ -282,3 +282,75 @@ def test_fused_spot_loss_leaves_the_traced_rays_to_be_made_on_demand(ns):
     assert torch.equal(ha[0][:, m], hb[0][:, m]) and torch.equal(wa[0][m], wb[0][m])
     assert torch.equal(rb._pos, src._pos) and not torch.equal(ra._pos, src._pos)
     assert len(grads) >= 4
+
+
+def test_second_device_in_one_process(ns):
+    """The grant of dynamic LDS above 64 KB is a property of a device's copy of the kernel: a process that sweeps on
+    cuda:0 and then on cuda:1 must get it on both (skipped on a one-GPU box)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    lib = N.lib()
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    prog = P.compile_elements([lens, sensor])
+    masks = np.zeros(4, dtype=np.uint32)
+    masks[0] = masks[1] = np.uint32((1 << 23) | (1 << 24))
+    outs = []
+    assert lib.rtt_tune(7, 1) == 0     # full states in LDS: about 100 KB for this program
+    try:
+        for dev in ("cuda:0", "cuda:1"):
+            n = 20001
+            rays = scenes.disk_bundle(ns, radius=4.0, z=-30.0).sample(n).to(dev)
+            adj = torch.ones(3, n, device=dev)
+            dp = N.DeviceProgram.upload(prog, dev)
+            slot_adj = torch.empty(4, dtype=torch.float64, device=dev)
+            ws = torch.empty(int(lib.rtt_trace_seq_adjoint_workspace_bytes(4)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                code = lib.rtt_trace_seq_adjoint_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev),
+                                                     dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj), 0, n, 0, n, -1, 0, 0.0, 0.0,
+                                                     1.0, 0, 0, 0, N.ptr(slot_adj), N.ptr(ws), ws.numel(), N.stream_handle(dev))
+            N.check(code, "rtt_trace_seq_adjoint_f32 on " + dev)
+            torch.cuda.synchronize(dev)
+            outs.append(slot_adj.cpu())
+    finally:
+        lib.rtt_tune(7, 0)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("state", [0, 1, 2])
+def test_state_placements_agree(ns, state):
+    """Compact states in LDS (the default for short programs), full states in LDS and states in registers sweep the
+    same formulas per ray.  Each placement is its own instantiation of the kernel, in which the compiler may contract
+    product-sums differently, so agreement is required to float32 rounding, not bit for bit."""
+    lib = N.lib()
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    prog = P.compile_elements([lens, sensor])
+    n = 300007
+    rays = scenes.disk_bundle(ns, radius=5.2, z=-30.0, rot=[0.01, 0.02, 0.0]).sample(n).to(DEV)   # some rays miss the lens
+    dp = N.DeviceProgram.upload(prog, DEV)
+    g = torch.Generator().manual_seed(9)
+    adj_pos, adj_dir = (torch.randn(3, n, generator=g).to(DEV) for _ in range(2))
+    adj_sens = torch.randn(1, 3, n, generator=g).to(DEV)
+    pairs = [(0, 23), (0, 24), (0, 26), (0, 30), (1, 23), (1, 24), (1, 31), (2, 24), (3, 21), (3, 23)]
+    masks = np.zeros(4, dtype=np.uint32)
+    for s, j in pairs:
+        masks[s] |= np.uint32(1 << j)
+
+    def run(which):
+        assert lib.rtt_tune(7, which) == 0
+        try:
+            slot_adj = torch.empty(len(pairs), dtype=torch.float64, device=DEV)
+            ray_adj = torch.empty((6, n), device=DEV)
+            ws = torch.empty(int(lib.rtt_trace_seq_adjoint_workspace_bytes(len(pairs))), dtype=torch.uint8, device=DEV)
+            code = lib.rtt_trace_seq_adjoint_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev),
+                                                 dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+                                                 -1, 0, 0.0, 0.0, 1.0, 0, N.ptr(ray_adj), n, N.ptr(slot_adj), N.ptr(ws), ws.numel(),
+                                                 N.stream_handle(DEV))
+            N.check(code, "rtt_trace_seq_adjoint_f32")
+            torch.cuda.synchronize()
+            return slot_adj.cpu(), ray_adj.cpu()
+        finally:
+            lib.rtt_tune(7, 0)
+    want, got = run(1), run(state)
+    worst = float((got[1] - want[1]).abs().max()) / float(want[1].abs().max())
+    assert worst <= 1e-5, worst
+    assert float((got[0] - want[0]).abs().max()) <= 1e-5 * float(want[0].abs().max())

@@ -154,6 +154,9 @@ def test_naive32_full_size(ns):
         got = getattr(rays, f)[idx].cpu().numpy()
         assert_parity(got[base], o[f].numpy()[base], o64[f].numpy()[base], what=f"naive step {f}", hard=True)
         assert_parity(got[rest], o[f].numpy()[rest], o64[f].numpy()[rest], what=f"stress bundle (32 surfaces) {f}")
+        # whatever the float64 tie-break would accept, the share of stress rays beyond the plain tolerance stays bounded
+        from util import ray_err
+        assert float(np.nanmean(ray_err(got[rest], o[f].numpy()[rest]) >= PARITY_TOL)) <= 1e-3, f
     assert np.array_equal((rays.intensity[idx].cpu().numpy() > 0)[same], (o["intensity"].numpy() > 0)[same])
     # a second bounce runs and leaves rays that missed everything untouched
     miss = ~hit
@@ -497,6 +500,33 @@ def test_staged_bounce_loop_equals_the_single_launch(ns, case, n, monkeypatch):
     assert ka.shape[0] > 0 and torch.equal(ka, kb) and torch.equal(ha, hb)
 
 
+def test_staged_entry_point_without_bounces_copies_the_rays_through(ns):
+    """rtt_simulate_nearest_staged_f32 with max_bounces = 0 runs no stage; like the single launch it must still write
+    every ray to its place and zero the bounce counts."""
+    from raytracetorch_amd import _native as N
+    lib = N.lib()
+    scene = ns.Scene()
+    for el in scenes.naive32(ns):
+        scene.add_element(el)
+    prog = scene._program()
+    n = 200001
+    src = device_disk_rays(ns, n, seed=3, radius=4.0, z=-10.0)
+    dp = N.DeviceProgram.upload(prog, DEV)
+    out_p, out_d, out_i = torch.full_like(src._pos, 7.0), torch.full_like(src._dir, 7.0), torch.full_like(src.intensity, 7.0)
+    bounces = torch.full((n,), 9, dtype=torch.int32, device=DEV)
+    count = torch.zeros((64, 32), dtype=torch.int32, device=DEV)
+    hit = torch.empty((64, 4), device=DEV)
+    keys = torch.empty((64, 2), dtype=torch.int32, device=DEV)
+    ws = torch.empty(int(lib.rtt_simulate_nearest_staged_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    code = lib.rtt_simulate_nearest_staged_f32(N.ptr(src._pos), N.ptr(src._dir), N.ptr(src.intensity), n, N.ptr(out_p), N.ptr(out_d),
+                                               N.ptr(out_i), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n, 0, N.ptr(bounces), N.ptr(hit),
+                                               N.ptr(keys), N.ptr(count), 64, 64, N.ptr(ws), ws.numel(), N.stream_handle(DEV))
+    assert code == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out_p, src._pos) and torch.equal(out_d, src._dir) and torch.equal(out_i, src.intensity)
+    assert int(bounces.abs().max()) == 0 and int(count.sum()) == 0
+
+
 def test_full_size_staged_loop_and_generated_trace_equal_their_plain_forms(ns, monkeypatch):
     """At the sizes of the benchmarks: the 100-bounce loop of 4 Mi rays over the 32 surfaces in stages against the
     single launch (rays, bounce counts, number and checksum of the sensor crossings), and sampling + tracing 64 Mi rays
@@ -536,3 +566,115 @@ def test_full_size_staged_loop_and_generated_trace_equal_their_plain_forms(ns, m
     for f in ("_pos", "_dir", "intensity", "id", "wavelength"):
         assert torch.equal(getattr(one, f), getattr(two, f)), f
     assert int((one.intensity > 0).sum()) > n // 2
+
+
+def test_spot_loss_at_the_size_one_gpu_holds_in_configuration_5(ns):
+    """The spot-size optimisation step (optim/goals.py:144-187 + backward) at 32 * 2^20 rays, the share of one GPU in
+    the 256 Mi-ray configuration: the reverse sweep then runs at its grid cap and every lane serves dozens of tiles.
+    The sums of the loss are plain sums over rays (optim/goals.py:165-183), so the full-size result is held against
+    32 chunks of 2^20 rays that go through other code: the chunks are traced by the general differentiable trace, their
+    hit lists reduced by torch in float64, and the gradient is put together from the chunk gradients,
+        dL/dtheta = sum_c dL_c/dtheta |centre fixed  -  (Gx dSx/dtheta + Gy dSy/dtheta) / W,
+    with Sx = sum w x, Sy = sum w y and G = sum of the per-ray loss adjoints (the centroid moves with theta).
+    Then the same step with a one-rank RCCL group as `scene.grad_group`: identical bits."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from raytracetorch_amd import kernels as K
+    n, chunk = 32 * 2 ** 20, 2 ** 20
+    lens, sensor = scenes.spot_system(ns, grads=True)
+    scene = ns.SequentialScene([lens, sensor]).to(DEV)
+    params = dict(c1=lens.shape.surfaces[0].c, c2=lens.shape.surfaces[1].c, t0=lens.shape.surfaces[0].transform.trans,
+                  t1=lens.shape.surfaces[1].transform.trans, ior=lens.ior_glass)
+    assert all(p.requires_grad and p.is_cuda for p in params.values())
+    b = ns.CollimatedDisk(radius=4.0, ray_id=0, device=DEV, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(DEV))
+    src = b.sample(n, seed=1000, offset=0)
+    src._pos   # generate now: the bundle is resident, as in the benchmark
+
+    class Resident(torch.nn.Module):
+        def sample(self, _n):
+            return ns.Rays.from_planes(src._pos, src._dir, src.intensity, src.id, src.wavelength)
+    loss_fn = ns.SpotSizeLoss(sensor, [Resident()], N_rays=n)
+
+    def full_step(group):
+        scene.grad_group = group
+        for p in params.values():
+            p.grad = None
+        loss = loss_fn(scene)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in params.items()}
+
+    loss, grads = full_step(None)
+    # the kernel's own first moments at full size (what the loss derives weight and centroid from)
+    mom = torch.zeros(6, device=DEV, dtype=torch.float64)
+    with torch.no_grad():
+        K.trace_sequential(src, scene._program(), moments=(0, mom), store=False)
+    W_k, Sx_k, Sy_k = mom[:3].tolist()
+
+    # ---- the chunks, first pass: weight and centroid ----
+    def chunk_rays(c):
+        a, e = c * chunk, (c + 1) * chunk
+        return ns.Rays.from_planes(src._pos[:, a:e].contiguous(), src._dir[:, a:e].contiguous(), src.intensity[a:e].contiguous(),
+                                   src.id[a:e].contiguous(), src.wavelength[a:e].contiguous())
+    W = Sx = Sy = 0.0
+    with torch.no_grad():
+        for c in range(n // chunk):
+            sensor.reset()
+            scene.simulate(chunk_rays(c))
+            locs, w, _ = sensor.getHitsTensors()
+            w = torch.where(w > 0, w, torch.zeros_like(w)).double()
+            W += float(w.sum()); Sx += float((w * locs[:, 0].double()).sum()); Sy += float((w * locs[:, 1].double()).sum())
+    cx, cy = Sx / W, Sy / W
+    assert abs(W_k - W) <= 1e-6 * W
+    assert abs(Sx_k / W_k - cx) <= 1e-6 * 6.0 and abs(Sy_k / W_k - cy) <= 1e-6 * 6.0   # relative to the sensor's radius
+    # ---- second pass: loss, adjoint sums and the three gradient vectors per chunk ----
+    plist = list(params.values())
+    L = Gx = Gy = 0.0
+    dL = [torch.zeros_like(p, dtype=torch.float64) for p in plist]
+    dSx = [torch.zeros_like(p, dtype=torch.float64) for p in plist]
+    dSy = [torch.zeros_like(p, dtype=torch.float64) for p in plist]
+    scene.grad_group = None
+    for c in range(n // chunk):
+        sensor.reset()
+        scene.simulate(chunk_rays(c))             # the general differentiable trace
+        locs, w, _ = sensor.getHitsTensors()
+        assert locs.requires_grad
+        wd = torch.where(w > 0, w, torch.zeros_like(w)).double().detach()
+        x, y = locs[:, 0].double(), locs[:, 1].double()
+        u = torch.sqrt(((x - cx) ** 2 + (y - cy) ** 2) * (wd / W))
+        Lc, Sxc, Syc = u.sum(), (wd * x).sum(), (wd * y).sum()
+        with torch.no_grad():
+            inv = torch.where(u > 0, (wd / W) / u, torch.zeros_like(u))
+            Gx += float(((x - cx) * inv).sum()); Gy += float(((y - cy) * inv).sum())
+        L += float(Lc)
+        for acc, obj in ((dL, Lc), (dSx, Sxc), (dSy, Syc)):
+            for a, g in zip(acc, torch.autograd.grad(obj, plist, retain_graph=True, allow_unused=True)):
+                if g is not None:
+                    a += g.double()
+    assert abs(float(loss) - L) <= 1e-6 * L, (float(loss), L)
+    for k, a, bx, by in zip(params, dL, dSx, dSy):
+        want = (a - (Gx * bx + Gy * by) / W).cpu()
+        got = grads[k].double().cpu()
+        live = want != 0     # masked translation components stay exactly zero
+        assert torch.equal(got == 0, want == 0), k
+        assert float(((got - want).abs()[live] / want.abs()[live]).max()) <= 1e-5, (k, got, want)
+
+    # ---- the same step with a process group of one rank over RCCL ----
+    made = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+        made = True
+    try:
+        loss_g, grads_g = full_step(dist.group.WORLD)
+        assert torch.equal(loss_g, loss)
+        for k in grads:
+            assert torch.equal(grads_g[k], grads[k]), k
+    finally:
+        scene.grad_group = None
+        if made:
+            dist.destroy_process_group()

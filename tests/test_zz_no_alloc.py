@@ -57,3 +57,42 @@ def test_static_scratch_entry_point_equals_the_workspace_one(ns):
     code = lib.rtt_trace_seq_adjoint_static_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n, many.ctypes.data,
               0, 0, n, 0, n, -1, 0, 0.0, 0.0, 1.0, 0, 0, 0, N.ptr(rays._pos), N.stream_handle(DEV))
     assert code == -2 and b"size" in lib.rtt_strerror(code)
+
+
+def test_static_entry_point_allocates_nothing_and_replays_in_a_graph(ns):
+    """After one preparing call per device (a call without rays does it: symbol lookup, LDS grant, code object load) the
+    entry point leaves the allocator's counters untouched, and a capture of it replays to the same bits."""
+    lib = N.lib()
+    lens, sensor = scenes.spot_system(ns, grads=False)
+    prog = P.compile_elements([lens, sensor])
+    pairs = [(0, 23), (0, 24), (1, 24), (1, 31), (3, 23)]
+    masks = np.zeros(4, dtype=np.uint32)
+    for s, j in pairs:
+        masks[s] |= np.uint32(1 << j)
+    n = 50001
+    rays = scenes.disk_bundle(ns, radius=4.0, z=-30.0).sample(n).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    adj_pos = torch.randn(3, n, generator=g).to(DEV)
+    dp = N.DeviceProgram.upload(prog, DEV)
+    slot_adj = torch.zeros(len(pairs), dtype=torch.float64, device=DEV)
+
+    def call(count, stream):
+        return lib.rtt_trace_seq_adjoint_static_f32(N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, count, N.ptr(dp.dev),
+                                                    dp.host_ptr, dp.n, masks.ctypes.data, N.ptr(adj_pos), 0, n, 0, n, -1, 0, 0.0, 0.0,
+                                                    1.0, 0, 0, 0, N.ptr(slot_adj), stream)
+    assert call(0, N.stream_handle(DEV)) == 0          # the preparing call: no rays, zeros in slot_adj
+    torch.cuda.synchronize()
+    assert float(slot_adj.abs().max()) == 0.0
+    before = (torch.cuda.memory_allocated(DEV), torch.cuda.memory_reserved(DEV))
+    assert call(n, N.stream_handle(DEV)) == 0
+    torch.cuda.synchronize()
+    assert (torch.cuda.memory_allocated(DEV), torch.cuda.memory_reserved(DEV)) == before
+    eager = slot_adj.clone()
+    assert float(eager.abs().max()) > 0.0
+    slot_adj.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert call(n, N.stream_handle(DEV)) == 0     # the capture stream is torch's current stream inside the context
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(slot_adj, eager)
