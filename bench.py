@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--tune-reduce-blocks", type=int, default=0, help="override the grid of the reducing kernels (experiment)")
     ap.add_argument("--tune-cull", type=int, default=-1, help="0: nearest-hit kernels test every surface (experiment)")
     ap.add_argument("--tune-adjoint-lane", type=int, default=0, help="rays per lane of the reverse-mode backward: 1, 2, 0 = automatic")
+    ap.add_argument("--tune-adjoint-rounds", type=int, default=0, help="rounds of resident blocks in the grid of the reverse-mode backward (experiment)")
     ap.add_argument("--tune-adjoint-state", type=int, default=-1, help="1: the reverse-mode backward keeps its states in LDS also for short programs")
     return ap.parse_args()
 
@@ -355,9 +356,9 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
         if dist is not None:
             scene.grad_group = dist.group.WORLD
         surfaces = 4
-        kernel = ("k_trace_seq<moments> + k_sum_partials + k_spot_moments + k_trace_seq_adjoint + k_sum_partials"
-                  if os.environ.get("RTT_BACKWARD", "adjoint") == "adjoint" else
-                  "k_trace_seq + k_spot_moments x2 + k_trace_seq_tangent<6, spot>")
+        kernel = {"tape": "k_trace_seq<moments, tape> + k_sum_partials + k_spot_moments + k_trace_seq_adjoint<tape> + k_sum_partials",
+                  "adjoint": "k_trace_seq<moments> + k_sum_partials + k_spot_moments + k_trace_seq_adjoint + k_sum_partials",
+                  "tangent": "k_trace_seq + k_spot_moments x2 + k_trace_seq_tangent<6, spot>"}[os.environ.get("RTT_BACKWARD", "adjoint")]
 
         class _Resident(torch.nn.Module):
             """Bundle stand-in for SpotSizeLoss: hands out the resident synthetic rays."""
@@ -471,6 +472,8 @@ def main():
         _native.check(_native.lib().rtt_tune(3, a.tune_cull), "rtt_tune")
     if a.tune_adjoint_lane:
         _native.check(_native.lib().rtt_tune(6, a.tune_adjoint_lane), "rtt_tune")
+    if a.tune_adjoint_rounds:
+        _native.check(_native.lib().rtt_tune(9, a.tune_adjoint_rounds), "rtt_tune")
     if a.tune_adjoint_state >= 0:
         _native.check(_native.lib().rtt_tune(7, a.tune_adjoint_state), "rtt_tune")
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTT_ABI_VERSION 5
+#define RTT_ABI_VERSION 6
 #define RTT_MAX_SURFACES 64 /* upper bound on n_surf accepted by every entry point */
 
 /* error codes */
@@ -227,6 +227,33 @@ int rtt_trace_seq_adjoint_static_f32(const float* pos_in, const float* dir_in, c
                                      double wsum, const double* spot_mom, float* ray_adj, int64_t ld_ray, double* slot_adj,
                                      void* stream);
 
+/* ---- the differentiable trace with a tape: what torch autograd keeps between the forward of scene/sequential.py:12-36
+ * and its backward (optim/goals.py:144-187, tests/test_optimize_singlet.py:66-116), reduced to what the backward cannot
+ * make again cheaply.  rtt_trace_seq_tape_f32 is rtt_trace_seq_f32 (mom_slot < 0) or rtt_trace_seq_moments_f32
+ * (mom_slot >= 0; then pos_out, dir_out, inten_out may all be NULL) that also fills `tape`: per surface that some ray of
+ * an aligned group of 128 rays hits, the direction in front of it and the path length of every ray of the group
+ * (16 B per ray and surface hit), and per group the set of those surfaces.  `tape` is device memory of
+ * rtt_trace_seq_tape_bytes(n, n_surf) bytes, 256-byte aligned, opaque to the caller.  prog_host is required.
+ * rtt_trace_seq_adjoint_tape_f32 is rtt_trace_seq_adjoint_f32 without its forward sweep: it reads the input positions
+ * and the tape of the same rays and program (the directions and intensities are not read), at about two thirds of the
+ * arithmetic.  spot_w: in spot mode, the device plane [n] of intensities the spot sensor recorded (sens_w of that slot
+ * as the forward call wrote it).  Limits: programs of at most 6 surfaces and rtt_trace_seq_adjoint_tape_max_slots(n_surf)
+ * slot sums per call (0 = no tape for this program: use rtt_trace_seq_adjoint_f32); RTT_E_SIZE beyond. */
+int64_t rtt_trace_seq_tape_bytes(int64_t n, int n_surf);
+int rtt_trace_seq_adjoint_tape_max_slots(int n_surf);
+int rtt_trace_seq_tape_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                           float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                           const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
+                           float* sens_hit, float* sens_w, uint8_t* sens_mask, int64_t sens_ld,
+                           int mom_slot, double* mom, void* workspace, int64_t workspace_bytes,
+                           void* tape, int64_t tape_bytes, void* stream);
+int rtt_trace_seq_adjoint_tape_f32(const float* pos_in, int64_t ld_in, int64_t n,
+                                   const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
+                                   const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
+                                   int spot_slot, int spot_centroid, double cx, double cy, double wsum, const double* spot_mom,
+                                   const float* spot_w, float* ray_adj, int64_t ld_ray, double* slot_adj, void* workspace,
+                                   int64_t workspace_bytes, const void* tape, int64_t tape_bytes, void* stream);
+
 /* ---- nearest-hit cast: Scene.ray_cast (scene/base.py:144-178) ---------------------------------
  * winner[i] = index of the first surface with the smallest t (or -1 when every t is inf),
  * tmin[i] = that t.  Either output may be NULL. */
@@ -421,9 +448,11 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * key 5: cap on the blocks of the other reducing kernels (tangent traces), default 2048;
  * key 6: rays per lane of rtt_trace_seq_adjoint_f32: 0 (default) two when the LDS need allows two blocks per compute
  * unit, else one; 1 or 2 force the choice;
- * key 7: where rtt_trace_seq_adjoint_f32 keeps the per-surface ray states and the slot sums: 0 (default) in registers
- * when the program has at most 4 surfaces and at most 64 slot sums are asked for, else in LDS; 1 always in LDS;
- * key 8: threads per block of rtt_spot_moments_f32 on 16-byte aligned records, 1024 (default) or 256.
+ * key 7: the per-surface ray states of rtt_trace_seq_adjoint_f32 in LDS: 0 (default) compact (direction and path length,
+ * positions walked again) for programs of at most 6 surfaces where that lets a third wavefront per SIMD in, 1 always
+ * the full states;
+ * key 8: threads per block of rtt_spot_moments_f32 on 16-byte aligned records, 1024 (default) or 256;
+ * key 9: size of the grid of the reverse sweeps in rounds of resident blocks, 1 .. 8 (default 3, at most 2048 blocks).
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

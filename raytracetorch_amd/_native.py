@@ -37,6 +37,10 @@ _SIGNATURES = {
                                   _int, _int, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
     "rtt_trace_seq_adjoint_static_f32": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
                                          _int, _int, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp],
+    "rtt_trace_seq_tape_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
+                               _vp, _vp, _vp, _i64, _int, _vp, _vp, _i64, _vp, _i64, _vp],
+    "rtt_trace_seq_adjoint_tape_f32": [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _i64, _vp, _i64,
+                                       _int, _int, _dbl, _dbl, _dbl, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "rtt_ray_cast_f32": [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp],
     "rtt_step_nearest_f32": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int,
                              _vp, _vp, _vp, _vp, _i64, _vp],
@@ -60,7 +64,8 @@ _SIGNATURES = {
 }
 EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune",
                                 "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes",
-                                "rtt_trace_seq_moments_workspace_bytes", "rtt_simulate_nearest_staged_workspace_bytes")
+                                "rtt_trace_seq_moments_workspace_bytes", "rtt_simulate_nearest_staged_workspace_bytes",
+                                "rtt_trace_seq_tape_bytes", "rtt_trace_seq_adjoint_tape_max_slots")
 
 
 class RttSource(ctypes.Structure):
@@ -106,6 +111,10 @@ def lib():
     L.rtt_trace_seq_moments_workspace_bytes.restype = _i64
     L.rtt_simulate_nearest_staged_workspace_bytes.argtypes = [_i64]
     L.rtt_simulate_nearest_staged_workspace_bytes.restype = _i64
+    L.rtt_trace_seq_tape_bytes.argtypes = [_i64, _int]
+    L.rtt_trace_seq_tape_bytes.restype = _i64
+    L.rtt_trace_seq_adjoint_tape_max_slots.argtypes = [_int]
+    L.rtt_trace_seq_adjoint_tape_max_slots.restype = _int
     if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
         raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")
     _lib = L

@@ -164,11 +164,20 @@ def _tangent_contract(rays_in, prog, table, adj_pos, adj_dir, adj_sens):
 
 
 def backward_mode() -> str:
-    """"adjoint" (reverse mode, the default) or "tangent" (forward mode) for the sequential trace."""
+    """How the sequential trace is differentiated: "adjoint" (reverse mode with a second trace inside the sweep, the
+    default), "tape" (reverse mode swept from a tape that the forward trace keeps, for programs short enough; measured
+    slower on the whole step: the tape costs the forward trace more HBM writes than the sweep saves arithmetic) or
+    "tangent" (forward mode)."""
     mode = os.environ.get("RTT_BACKWARD", "adjoint")
-    if mode not in ("adjoint", "tangent"):
-        raise ValueError("RTT_BACKWARD must be 'adjoint' or 'tangent'")
+    if mode not in ("adjoint", "tape", "tangent"):
+        raise ValueError("RTT_BACKWARD must be 'adjoint', 'tape' or 'tangent'")
     return mode
+
+
+def keeps_tape(prog) -> bool:
+    """Whether a differentiable trace of this program keeps a tape for its backward (16 B per ray and surface hit
+    instead of a second trace): only when asked for, and for a program short enough for the sweep that reads tapes."""
+    return backward_mode() == "tape" and K.tape_slots(prog.shape[0]) > 0
 
 
 def _slot_pairs(table):
@@ -200,16 +209,18 @@ def _adjoint_plan(table, budget, dev, derived=None):
 
 
 def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=None, want_ray_adj=False, spot=None,
-                   derived=None):
+                   derived=None, tape=None, spot_w=None):
     """Reverse-mode backward of the sequential trace: (d objective / d theta [n_theta] float64 on the device,
     [6, N] adjoint of the input rays or None).  The objective is given by the upstream adjoints of the output planes
     and of the sensor records, or, with `spot` = (sensor slot, centroid?, target x, target y, device tensor of the six
     moment sums), by the spot-size loss whose adjoint the kernel forms itself from those sums.  Returns None when the
-    program is too long for the kernel's LDS budget (the caller then uses the forward-mode kernels)."""
+    program is too long for the kernel's LDS budget (the caller then uses the forward-mode kernels).  `tape` (a
+    `kernels.Tape` of the same rays and program; in spot mode with `spot_w`, the intensities that sensor recorded)
+    replaces the sweep's own forward trace."""
     n, dev = len(rays_in), rays_in.device
     n_surf, n_theta = table.shape[0], table.shape[2]
     lib = N.lib()
-    budget = lib.rtt_trace_seq_adjoint_max_slots(n_surf)
+    budget = K.tape_slots(n_surf) if tape is not None else lib.rtt_trace_seq_adjoint_max_slots(n_surf)
     if budget == 0:
         return None
     dtheta = torch.zeros(n_theta, dtype=torch.float64, device=dev)
@@ -227,13 +238,21 @@ def _adjoint_sweep(rays_in, prog, table, adj_pos=None, adj_dir=None, adj_sens=No
         ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
         first = c == 0
         with torch.cuda.device(dev):
-            code = lib.rtt_trace_seq_adjoint_f32(
-                N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
-                N.ptr(dp.dev), dp.host_ptr, dp.n, masks.ctypes.data,
-                N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
-                int(slot), int(bool(centroid)), float(cx), float(cy), 1.0, N.ptr(mom_dev),
-                N.ptr(ray_adj) if first else 0, n, N.ptr(slot_adj), N.ptr(ws), ws_bytes, N.stream_handle(dev))
-        N.check(code, "rtt_trace_seq_adjoint_f32")
+            if tape is not None:
+                code = lib.rtt_trace_seq_adjoint_tape_f32(
+                    N.ptr(rays_in._pos), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n, masks.ctypes.data,
+                    N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+                    int(slot), int(bool(centroid)), float(cx), float(cy), 1.0, N.ptr(mom_dev), N.ptr(spot_w),
+                    N.ptr(ray_adj) if first else 0, n, N.ptr(slot_adj), N.ptr(ws), ws_bytes, N.ptr(tape.buf), tape.buf.numel(),
+                    N.stream_handle(dev))
+            else:
+                code = lib.rtt_trace_seq_adjoint_f32(
+                    N.ptr(rays_in._pos), N.ptr(rays_in._dir), N.ptr(rays_in.intensity), n, n,
+                    N.ptr(dp.dev), dp.host_ptr, dp.n, masks.ctypes.data,
+                    N.ptr(adj_pos), N.ptr(adj_dir), n, N.ptr(adj_sens), n,
+                    int(slot), int(bool(centroid)), float(cx), float(cy), 1.0, N.ptr(mom_dev),
+                    N.ptr(ray_adj) if first else 0, n, N.ptr(slot_adj), N.ptr(ws), ws_bytes, N.stream_handle(dev))
+        N.check(code, "rtt_trace_seq_adjoint_tape_f32" if tape is not None else "rtt_trace_seq_adjoint_f32")
         if n_acc:
             contribution = slot_adj[:n_acc] @ rows
             dtheta = contribution if len(plan) == 1 else dtheta + contribution
@@ -272,7 +291,11 @@ class TraceSeqFn(torch.autograd.Function):
         # the kernel writes every ray of `out`, so fresh uninitialised planes are enough
         out = Rays.from_planes(torch.empty_like(rays_in._pos), torch.empty_like(rays_in._dir),
                                torch.empty_like(rays_in.intensity), rays_in.id, rays_in.wavelength)
-        sens_hit, sens_w, sens_mask = K.trace_sequential(rays_in, prog, out=out)
+        ctx.tape = None
+        if keeps_tape(prog):
+            sens_hit, sens_w, sens_mask, ctx.tape = K.trace_sequential(rays_in, prog, out=out, tape=True)
+        else:
+            sens_hit, sens_w, sens_mask = K.trace_sequential(rays_in, prog, out=out)
         ctx.rays_in, ctx.prog, ctx.table, ctx.thetas, ctx.group = rays_in, prog, table, thetas, group
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
@@ -289,8 +312,8 @@ class TraceSeqFn(torch.autograd.Function):
             g_sens = None
         want_rays = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
         swept = None
-        if backward_mode() == "adjoint":   # one reverse sweep yields both kinds of gradient
-            swept = _adjoint_sweep(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens, want_ray_adj=want_rays)
+        if backward_mode() != "tangent":   # one reverse sweep yields both kinds of gradient
+            swept = _adjoint_sweep(ctx.rays_in, ctx.prog, ctx.table, g_pos, g_dir, g_sens, want_ray_adj=want_rays, tape=ctx.tape)
         g_pos_in = g_dir_in = None
         if swept is not None:
             dtheta, adj = swept
@@ -559,13 +582,14 @@ class FusedSpotLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_in, prog, table, thetas, group, target, sensor_slot, sens, mom, *params):
         table, derived = table   # the slot Jacobians and the dict of device objects derived from them
-        hit, w, mask = sens  # dense record of the sensor slot from the forward trace
+        hit, w, mask = sens[:3]  # dense record of the sensor slot from the forward trace
+        tape = sens[3] if len(sens) > 3 else None   # and what that trace kept for the reverse sweep, if it kept a tape
         x, y = hit[0], hit[1]
         n, dev = len(rays_in), rays_in.device
         ctx.thetas, ctx.derived = thetas, derived
         ctx.param_meta = [(p.shape, p.dtype, p.device) for p in params]
         ctx.param_ids = [id(p) for p in params]
-        if backward_mode() == "adjoint" and N.lib().rtt_trace_seq_adjoint_max_slots(int(table.shape[0])) > 0:
+        if backward_mode() != "tangent" and (tape is not None or N.lib().rtt_trace_seq_adjoint_max_slots(int(table.shape[0])) > 0):
             # Reverse mode, without a host round trip: the six moment sums stay on the device.  `mom` holds this rank's
             # first moments (pass 0, launched by the caller); the second pass reads weight and centroid from it and adds
             # the loss sum and the centroid term (Gx, Gy); the reverse sweep reads all of them and yields the slot
@@ -577,7 +601,8 @@ class FusedSpotLossFn(torch.autograd.Function):
             allreduce_sum_(mom[3:6], group)
             # nothing lit on any rank: every sum is zero and no ray carries a seed, so loss and gradients come out as
             # zeros by themselves; `lit` only tells the caller not to count this bundle (optim/goals.py:165-167)
-            dtheta, _ = _adjoint_sweep(rays_in, prog, table, spot=(sensor_slot, centroid, tx, ty, mom), derived=derived)
+            dtheta, _ = _adjoint_sweep(rays_in, prog, table, spot=(sensor_slot, centroid, tx, ty, mom), derived=derived,
+                                       tape=tape, spot_w=w if tape is not None else None)
             allreduce_sum_(dtheta, group)
             ctx.dtheta = dtheta
             out = mom.to(torch.float32)   # one conversion: the loss and the lit weight are views of it
@@ -660,7 +685,7 @@ def fused_spot_loss(elements, rays, prog, sensor_slot, sens, target=None, group=
     Returns (loss, lit): `lit` is a 0/1 tensor on the device, 0 when nothing lit reached the sensor on any rank (the
     reference skips such a bundle, optim/goals.py:165-167; the loss is then 0 with zero gradients).  Neither is read
     on the host here, so the caller's step stays asynchronous."""
-    hit, w, mask = sens
+    hit, w, mask = sens[:3]
     if mom is None:   # (a caller whose trace already summed the first moments hands them in: six float64, three filled)
         # first moments right behind the trace; the host work below overlaps both kernels
         mom = torch.zeros(6, device=w.device, dtype=torch.float64)

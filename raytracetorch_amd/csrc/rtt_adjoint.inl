@@ -21,6 +21,41 @@
 
 constexpr int kAdjState = 7;  // floats kept per surface and ray: p (3), d (3), t
 
+// Phase clocks of the profiling build (-DRTT_PHASE_TIMERS=1, `make prof`): every wavefront adds up the shader clock
+// between marks (after waiting for everything it has in flight, so that a wait is charged to the phase that caused it)
+// and the kernel's sums end up in g_phase[], read by rtt_debug_phases().  The product build has no marks.
+#ifndef RTT_PHASE_TIMERS
+#define RTT_PHASE_TIMERS 0
+#endif
+constexpr int kPhases = 16;
+#if RTT_PHASE_TIMERS
+__device__ unsigned long long g_phase[kPhases];
+struct PhaseTimer {
+  uint64_t prev, acc[kPhases];
+  DI void start() {
+#pragma unroll
+    for (int k = 0; k < kPhases; ++k) acc[k] = 0;
+    prev = __builtin_readcyclecounter();
+  }
+  template <int K> DI void mark() {
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint64_t now = __builtin_readcyclecounter();
+    acc[K] += now - prev;
+    prev = now;
+  }
+  DI void flush() {
+    if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+      for (int k = 0; k < kPhases; ++k) atomicAdd(&g_phase[k], (unsigned long long)acc[k]);
+    }
+  }
+};
+#define RTT_MARK(tm, k) (tm)->template mark<k>()
+#else
+struct PhaseTimer {};
+#define RTT_MARK(tm, k) ((void)0)
+#endif
+
 // Which record slots of which surface get an accumulator: bit j of mask[s] = slot j (Rs 0-8, ts 9-11, Rj 12-20,
 // tj 21-23, geom 24-27, phys 28-31); the accumulators of a surface are consecutive, in slot order, from base[s].
 struct AccMap {
@@ -47,6 +82,12 @@ struct AdjointIO {
   int64_t ld_ray;
   double* partials;  // [gridDim.x][n_acc] block sums of the slot adjoints
   int n_acc;
+  // sweep from a tape (TAPE kernels): what the forward trace kept, see TapeIO; spot_w = the intensities the spot
+  // sensor recorded, [n] (the reverse sweep does not follow intensities)
+  const float* tape_planes;
+  int64_t tape_ld;
+  const uint64_t* tape_groups;
+  const float* spot_w;
 };
 
 template <class T>
@@ -57,6 +98,7 @@ struct SlotSink {
   int base;
   typename LaneOf<T>::M on;  // components whose contribution counts: hit and part of the bundle
   bool all_on;               // `on` holds for the whole wavefront: no select needed
+  PhaseTimer* tm;            // profiling build only
   DI bool wants(int slot) const { return (mask >> slot) & 1u; }
   DI bool wants_any(uint32_t slots) const { return (mask & slots) != 0u; }
   DI void add(int slot, T v) const {
@@ -65,45 +107,6 @@ struct SlotSink {
     const float x = all_on ? hsum(v) : hsum(sel(on, v, splat<T>(0.0f)));
     // the column belongs to this lane alone: a plain read-modify-write (an LDS atomic add measured slower)
     acc[a * stride] += x;
-  }
-};
-
-// Sum of a float over the 64 lanes of the wavefront with data-parallel-primitive adds (no LDS): lanes exchange within
-// quads, then within rows of 16 (mirrors), then lane 15 / 31 of a row is broadcast into the following rows; lane 63
-// ends up with the total, which is returned to every lane through a scalar register.
-template <int CTRL, int ROW_MASK>
-DI float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
-  return v + __builtin_bit_cast(float, moved);
-}
-DI float wave_total(float v) {
-  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane of a row holds the row's sum
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// The sink of the register-resident sweep: no per-lane accumulators at all.  A contribution is summed over the
-// wavefront at once (float32 over 64 or 128 values) and added, in float64, to accumulator a, which lives in lane a of
-// one register pair of the wavefront: up to 64 accumulators cost two registers, and the index a may be any
-// wave-uniform run-time value.
-template <class T>
-struct WaveSink {
-  double* acc;    // the wavefront's accumulator register (lane a = accumulator a)
-  uint32_t mask;  // wanted slots of the surface (wave-uniform)
-  int base;
-  typename LaneOf<T>::M on;
-  bool all_on;
-  DI bool wants(int slot) const { return (mask >> slot) & 1u; }
-  DI bool wants_any(uint32_t slots) const { return (mask & slots) != 0u; }
-  DI void add(int slot, T v) const {
-    if (!wants(slot)) return;  // scalar branch
-    const int a = base + __builtin_popcount(mask & ((1u << slot) - 1u));
-    const float x = wave_total(all_on ? hsum(v) : hsum(sel(on, v, splat<T>(0.0f))));
-    if ((int)(threadIdx.x & 63u) == a) *acc += (double)x;
   }
 };
 
@@ -379,20 +382,24 @@ DI void visit_adjoint(const RecF& S, V3<T> p, V3<T> d, T t, M hit, V3<T>& pb, V3
   const V3<T> nl = surface_normal<C>(S, hl);
   const V3<T> n1 = rowmat_t<1>(nl, S, idj);
   const V3<T> n = shp ? rowmat_t<0>(n1, S, ids) : n1;
+  RTT_MARK(sk.tm, 4);
   // ---- physics: new_dir(hl, d, n) ----
   V3<T> hlb = ext(hl);
   V3<T> dpb, nb;
   physics_adjoint<C>(S, hl, d, n, db, dpb, nb, hlb, ridx, sk);
+  RTT_MARK(sk.tm, 5);
   // ---- normal: n = (nl @ Rj^T) @ Rs^T ----
   const V3<T> n1b = shp ? rowmat<0>(nb, S, ids) : nb;
   const V3<T> nlb = rowmat<1>(n1b, S, idj);
   normal_adjoint<C>(S, hl, nl, nlb, hlb, sk);
+  RTT_MARK(sk.tm, 6);
   // ---- hit_local = pl + t dl, hit_global = p + t d ----
   V3<T> plb = hlb, dlb = scale(t, hlb);
   const T tb = dot3(hlb, dl) + dot3(pb, d);
   V3<T> p_in = pb;
   V3<T> d_in = dpb + scale(t, pb);
   root_adjoint<C>(S, pl, dl, t, hl, tb, plb, dlb, sk);
+  RTT_MARK(sk.tm, 7);
   // ---- frames: pl = (pe - tj) @ Rj, dl = den @ Rj, den = de / |de|, pe = (p - ts) @ Rs, de = d @ Rs ----
   const V3<T> ub = rowmat_t<1>(plb, S, idj);
   const V3<T> denb = rowmat_t<1>(dlb, S, idj);
@@ -432,6 +439,7 @@ DI void visit_adjoint(const RecF& S, V3<T> p, V3<T> d, T t, M hit, V3<T>& pb, V3
     pb = sel3(hit, p_in, pb);
     db = sel3(hit, d_in, db);
   }
+  RTT_MARK(sk.tm, 8);
   (void)zero;
 }
 
@@ -456,7 +464,13 @@ template <class I> DI f2 ldp_(const float* p, I i, bool vec, int nv, f2*) {
   return f2{p[i], p[i + (nv - 1)]};
 }
 
-// f(S), f(S + 1), ..., f(E - 1) and f(S), f(S - 1), ..., f(0) with the index a compile-time constant in every call
+// a 64-bit value that every lane of the wavefront holds alike, moved to scalar registers
+DI uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// f(S), f(S + 1), ..., f(E - 1) with the index a compile-time constant in every call
 template <int S, int E, class F>
 DI void unrolled(F&& f) {
   if constexpr (S < E) {
@@ -464,14 +478,6 @@ DI void unrolled(F&& f) {
     unrolled<S + 1, E>(f);
   }
 }
-template <int S, class F>
-DI void unrolled_down(F&& f) {
-  if constexpr (S >= 0) {
-    f(S);
-    unrolled_down<S - 1>(f);
-  }
-}
-
 // Where the forward sweep keeps the state in front of every surface.
 // LDS (NS == 0): a lane-private column of dynamic LDS, any number of surfaces, rolled loops.  Per surface either the
 // full state (position, direction, path length: 7 values) or, COMPACT, direction and path length only (4 values) next
@@ -481,6 +487,7 @@ DI void unrolled_down(F&& f) {
 // quadratic in the number of surfaces; it is used for short programs, where the smaller footprint buys a third
 // wavefront per SIMD.
 constexpr int kAdjStateCompact = 4, kAdjStart = 3;
+constexpr int kAdjCompactSurfaces = 6;  // longest program swept with compact states (the walk is quadratic)
 template <class T, int BS, bool COMPACT>
 struct AdjState {
   static constexpr int kPer = COMPACT ? kAdjStateCompact : kAdjState;
@@ -512,38 +519,29 @@ struct AdjState {
     t = st[6 * BS];
   }
 };
-// Registers (NS > 0): programs of at most NS surfaces; the surface loops are unrolled so that every index below is a
-// compile-time constant and the arrays never leave the register file.
-template <class T, int BS, int NS>
-struct AdjStateReg {
-  V3<T> p[NS], d[NS];
-  T t[NS];
-  DI AdjStateReg(float*, int) {}
-  DI void put(int s, V3<T> pp, V3<T> dd, T tt) { p[s] = pp; d[s] = dd; t[s] = tt; }
-  DI void get(int s, V3<T>& pp, V3<T>& dd, T& tt) const { pp = p[s]; dd = d[s]; tt = t[s]; }
-};
-
-// NS == 0: dynamic LDS = float acc[n_acc][BS], then T state[n_surf][7][BS] or, COMPACT, T start[3][BS] and
+// Dynamic LDS = float acc[n_acc][BS], then T state[n_surf][7][BS] or, COMPACT, T start[3][BS] and
 //   T state[n_surf][4][BS]; BS threads per block.  With two rays per lane a four-surface program gets two wavefronts
 //   per SIMD with the full states and three with the compact ones.
-// NS > 0 (n_surf <= NS, n_acc <= 64): state in registers, slot sums in one lane-indexed register pair per wavefront;
-//   no dynamic LDS, occupancy set by the register count alone.
-template <class T, int BS, int NS, bool COMPACT = false>
+// TAPE (with COMPACT): there is no forward sweep; the states come from the tape the forward trace wrote (direction and
+//   path length per surface that the ray's group hit), staged into the same LDS layout, and the positions are walked
+//   from the input positions as above.  io.dir_in and io.inten_in are not read.
+template <class T, int BS, bool COMPACT = false, bool TAPE = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT ? 3 : 2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                               Ops ops, AccMap am, AdjointIO a, int vec) {
-  static_assert(!(COMPACT && NS > 0), "the compact states are an LDS layout");
+  static_assert(!TAPE || (COMPACT && LaneOf<T>::N == 2 && BS % 64 == 0), "a tape is swept with compact states, two rays per lane");
   extern __shared__ float lds_dyn[];
-  __shared__ double wave_acc[NS > 0 ? (BS / 64) * 64 : 1];
   constexpr int N = LaneOf<T>::N;
-  constexpr bool REG = NS > 0;
   using M = typename LaneOf<T>::M;
-  using State = typename std::conditional<REG, AdjStateReg<T, BS, REG ? NS : 1>, AdjState<T, BS, COMPACT>>::type;
-  using Sink = typename std::conditional<REG, WaveSink<T>, SlotSink<T>>::type;
+  using State = AdjState<T, BS, COMPACT>;
+  using Sink = SlotSink<T>;
   const RttSurface* __restrict__ prog = (const RttSurface*)__builtin_assume_aligned(prog_, 256);
   float* acc = lds_dyn + threadIdx.x;
-  double racc = 0.0;  // REG: accumulator `lane` of this wavefront
-  if (!REG)
-    for (int k = 0; k < a.n_acc; ++k) acc[k * BS] = 0.0f;
+  PhaseTimer timer, *tm = &timer;
+#if RTT_PHASE_TIMERS
+  timer.start();
+#endif
+  (void)tm;
+  for (int k = 0; k < a.n_acc; ++k) acc[k * BS] = 0.0f;
   float Gx = 0.0f, Gy = 0.0f, cx = a.cx, cy = a.cy, inv_w = a.inv_w;
   if (a.spot_slot >= 0 && a.spot_mom) {
     const double W = fmax(a.spot_mom[0], 1e-12);  // the reference clamps the weight sum (optim/goals.py:173)
@@ -557,16 +555,31 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
   }
   const int64_t tile = (int64_t)BS * N;
   const int64_t stride = (int64_t)gridDim.x * tile;
+  uint64_t group_mask = 0ull;  // TAPE: surfaces the group of the next tile hit (wave-uniform, kept in scalar registers)
+  if constexpr (TAPE) {
+    const int64_t first = (int64_t)blockIdx.x * tile + (int64_t)(threadIdx.x & ~63u) * N;
+    if (first < io.n) group_mask = uniform64(a.tape_groups[first / kTapeGroup]);
+  }
   for (int64_t base = (int64_t)blockIdx.x * tile; base < io.n; base += stride) {
     const RayIO tio = {io.pos_in + base, io.dir_in + base, io.inten_in + base, io.ld_in, nullptr, nullptr, nullptr, 0, io.n - base};
     const uint32_t idx = threadIdx.x * N;
     const int64_t left = tio.n - (int64_t)idx;
     const int nv = left >= N ? N : (left >= 1 ? 1 : 0);
     // lanes past the end trace a copy of the tile's first ray and contribute nothing
-    Ray<T> r = load_ray<T>(tio, nv ? idx : 0u, vec != 0 && nv == N, nv ? nv : 1);
+    Ray<T> r;
+    if constexpr (TAPE) {
+      T* tagp = nullptr;
+      const uint32_t ati = nv ? idx : 0u;
+      const bool vl = vec != 0 && nv == N;
+      r.p = {ld_(tio.pos_in, ati, vl, nv ? nv : 1, tagp), ld_(tio.pos_in + tio.ld_in, ati, vl, nv ? nv : 1, tagp),
+             ld_(tio.pos_in + 2 * tio.ld_in, ati, vl, nv ? nv : 1, tagp)};
+    } else {
+      r = load_ray<T>(tio, nv ? idx : 0u, vec != 0 && nv == N, nv ? nv : 1);
+    }
     M live = mask_all<M>(false);
 #pragma unroll
     for (int k = 0; k < N; ++k) live = set_mask(live, k, k < nv);
+    RTT_MARK(tm, 0);  // ray loads
     const uint64_t ridx = (uint64_t)(base + idx);
     HitBits<T> bits;
 #pragma unroll
@@ -577,7 +590,6 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
     if constexpr (COMPACT) state.put_start(r.p);
     // ---- forward sweep: keep the state in front of every surface that is hit ----
     auto forward_visit = [&](const int s) __attribute__((always_inline)) {
-      if (REG && s >= n_surf) return;
       const RecF S{prog[s]};
       Frames<T> f;
       T t_raw;
@@ -609,11 +621,46 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
 #undef RTT_CALL
       set_bits(bits, s, hit);
     };
-    if constexpr (REG) {
-      unrolled<0, NS>(forward_visit);
+    if constexpr (TAPE) {
+      // ---- no forward sweep: stage the tape of this wavefront's group ----
+      // All loads of a tile are issued before the first one is waited for (one trip to memory per tile, not one per
+      // surface), and the group's surface mask was asked for a tile ahead.
+      any_hit = group_mask;
+      {
+        const int64_t next_first = base + stride + (int64_t)(threadIdx.x & ~63u) * N;
+        group_mask = next_first < io.n ? uniform64(a.tape_groups[next_first / kTapeGroup]) : 0ull;
+      }
+      T* tagp = nullptr;
+      const uint32_t ati = nv ? idx : 0u;
+      const bool vl = vec != 0 && nv == N;
+      if (a.spot_slot >= 0 && a.spot_w) w_spot = ld_(a.spot_w + base, ati, vl, nv ? nv : 1, tagp);
+      constexpr int kBatch = 3;  // surfaces whose planes are in flight together (their values wait in registers)
+      uint64_t left_s = any_hit;
+      while (left_s != 0ull) {
+        int sb[kBatch];
+        V3<T> dq[kBatch];
+        T tq[kBatch];
+        unrolled<0, kBatch>([&](const int j) __attribute__((always_inline)) {
+          sb[j] = left_s != 0ull ? __builtin_ctzll(left_s) : -1;
+          left_s &= left_s - 1ull;
+          if (sb[j] < 0) return;
+          const float* tp = a.tape_planes + (int64_t)4 * sb[j] * a.tape_ld + base;
+          dq[j] = {ld_(tp, ati, vl, nv ? nv : 1, tagp), ld_(tp + a.tape_ld, ati, vl, nv ? nv : 1, tagp),
+                   ld_(tp + 2 * a.tape_ld, ati, vl, nv ? nv : 1, tagp)};
+          tq[j] = ld_(tp + 3 * a.tape_ld, ati, vl, nv ? nv : 1, tagp);
+        });
+        unrolled<0, kBatch>([&](const int j) __attribute__((always_inline)) {
+          if (sb[j] < 0) return;
+          const M hit = and_(gt(tq[j], splat<T>(0.0f)), live);   // a ray that missed carries t = -1
+          state.put(sb[j], r.p, dq[j], tq[j]);
+          if (__all(all_(hit))) all_hit |= 1ull << sb[j];
+          set_bits(bits, sb[j], hit);
+        });
+      }
     } else {
       for (int s = 0; s < n_surf; ++s) forward_visit(s);
     }
+    RTT_MARK(tm, 1);  // forward sweep (or the staging of the tape)
     // ---- adjoint of the final state ----
     T* tag = nullptr;
     const T zero = splat<T>(0.0f);
@@ -632,7 +679,6 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
     }
     // ---- reverse sweep ----
     auto reverse_visit = [&](const int s) __attribute__((always_inline)) {
-      if (REG && s >= n_surf) return;
       const M hit = get_bits(bits, s);
       if (!__any(any_(hit))) return;
       const RecF S{prog[s]};
@@ -654,9 +700,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
       }
       const M on = and_(hit, live);
       const bool all_on = __all(all_(on));
-      Sink sk;
-      if constexpr (REG) sk = Sink{&racc, am.mask[s], (int)am.base[s], on, all_on};
-      else sk = Sink{acc, BS, am.mask[s], (int)am.base[s], on, all_on};
+      const Sink sk = {acc, BS, am.mask[s], (int)am.base[s], on, all_on, tm};
+      RTT_MARK(tm, 2);  // upstream adjoints, state of the visit, positions walked
       const bool sensor = (S.r.flags & RTT_F_SENSOR) != 0;
       const int slot = S.r.sensor_slot;
       auto ext = [&](V3<T> hl) -> V3<T> {
@@ -668,7 +713,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
           const T dx = hl.x - cx, dy = hl.y - cy;
           const T uu = sqrt_ieee((dx * dx + dy * dy) * wn);
           const T inv = sel(gt(uu, zero), div_ieee(wn, uu), zero);
-          const auto on = gt(w_spot, zero);
+          const auto on = and_(gt(w_spot, zero), hit);  // (a recorded intensity exists only where the sensor was hit)
           g.x = sel(on, dx * inv - wn * Gx, zero);
           g.y = sel(on, dy * inv - wn * Gy, zero);
           return g;
@@ -683,15 +728,12 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
         }
         return g;
       };
+      RTT_MARK(tm, 3);  // record flags, dispatch
 #define RTT_CALL(CFG) visit_adjoint<CFG>(S, p, d, t, hit, pb, db, ridx, sk, ext)
       RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     };
-    if constexpr (REG) {
-      unrolled_down<NS - 1>(reverse_visit);
-    } else {
-      for (int s = n_surf - 1; s >= 0; --s) reverse_visit(s);
-    }
+    for (int s = n_surf - 1; s >= 0; --s) reverse_visit(s);
     if (a.ray_adj && nv) {
       float* ra = a.ray_adj + base;
       const T comps[6] = {pb.x, pb.y, pb.z, db.x, db.y, db.z};
@@ -704,27 +746,20 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
       }
     }
   }
+  RTT_MARK(tm, 9);
+#if RTT_PHASE_TIMERS
+  timer.flush();
+#endif
   // ---- block sums of the slot adjoints, float64 ----
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if constexpr (REG) {
-    wave_acc[wv * 64 + lane] = racc;
-    __syncthreads();
-    if (wv == 0 && lane < a.n_acc) {
-      double v = 0.0;
+  __syncthreads();
+  for (int k = wv; k < a.n_acc; k += BS / 64) {
+    const float* col = lds_dyn + (int64_t)k * BS;
+    double v = 0.0;
 #pragma unroll
-      for (int j = 0; j < BS / 64; ++j) v += wave_acc[j * 64 + lane];
-      a.partials[(int64_t)blockIdx.x * a.n_acc + lane] = v;
-    }
-  } else {
-    __syncthreads();
-    for (int k = wv; k < a.n_acc; k += BS / 64) {
-      const float* col = lds_dyn + (int64_t)k * BS;
-      double v = 0.0;
-#pragma unroll
-      for (int j = 0; j < BS / 64; ++j) v += (double)col[lane + 64 * j];
-      v = wave_sum(v);
-      if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;  // read back by k_sum_partials with strides (n_acc, 1)
-    }
+    for (int j = 0; j < BS / 64; ++j) v += (double)col[lane + 64 * j];
+    v = wave_sum(v);
+    if (lane == 0) a.partials[(int64_t)blockIdx.x * a.n_acc + k] = v;  // read back by k_sum_partials with strides (n_acc, 1)
   }
 }
 

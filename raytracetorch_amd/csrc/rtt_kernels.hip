@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -1303,11 +1304,25 @@ struct GenIO {
   float* wavelength;  // [n] or null
 };
 
-template <class T, int G, bool LDS_PROG, bool MOM = false, bool GEN = false>
+// TAPE: the trace leaves what a later reverse sweep needs to differentiate it without tracing again (the tape of
+// torch autograd, reduced to what cannot be made again cheaply): for every surface s that some ray of an aligned group
+// of kTapeGroup rays hits, the direction in front of the surface and the path length t of every ray of the group
+// (t = -1 for a ray that misses: a kept root is > 1e-6), planes[(4 s + c) * ld + i], c = 0..2 direction, 3 path length;
+// and per group the set of those surfaces as a bit mask, groups[i / kTapeGroup].  Nothing is written for a surface no ray
+// of the group hits.  A group is the 128 rays of one wavefront (two rays per lane).
+constexpr int kTapeGroup = 128;
+struct TapeIO {
+  float* planes;
+  int64_t ld;
+  uint64_t* groups;
+};
+
+template <class T, int G, bool LDS_PROG, bool MOM = false, bool GEN = false, bool TAPE = false>
 __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                       Ops ops, SensorIO se, int vec, double* __restrict__ mom_partials = nullptr,
-                                                      GenIO gen = GenIO{}) {
+                                                      GenIO gen = GenIO{}, TapeIO tape = TapeIO{}) {
   static_assert(!GEN || (G == 1 && LaneOf<T>::N == 2), "generated rays come in pairs, one pair per lane");
+  static_assert(!TAPE || (G == 1 && LaneOf<T>::N == 2 && kBlock % 64 == 0), "a tape group is the two-ray lanes of one wavefront");
   __shared__ RttSurface lds_prog[LDS_PROG ? RTT_MAX_SURFACES : 1];
   __shared__ double mom_wave[MOM ? 3 * (kBlock / 64) : 1];
   float lane_mom[3] = {0.0f, 0.0f, 0.0f};
@@ -1369,12 +1384,40 @@ __global__ void __launch_bounds__(kBlock) k_trace_seq(RayIO io, const RttSurface
         r[g] = load_ray<T>(tio, nv[g] ? idx[g] : 0u, vec != 0 && nv[g] == N, nv[g] ? nv[g] : 1);
       }
     }
+    uint64_t group_hits = 0ull;  // TAPE: surfaces hit by some ray of this wavefront's group (wave-uniform)
     for (int s = 0; s < n_surf; ++s) {
       typename std::conditional<LDS_PROG, RecL, RecF>::type S{LDS_PROG ? lds_prog[s] : prog[s]};
+      if constexpr (TAPE) {
+#define RTT_CALL(CFG)                                                                                   \
+  {                                                                                                     \
+    Frames<T> f;                                                                                        \
+    T t_raw;                                                                                            \
+    const auto hit = test_surface<CFG>(S, r[0].p, r[0].d, f, t_raw);                                    \
+    if (__any(any_(hit))) {                                                                             \
+      group_hits |= 1ull << s;                                                                          \
+      if (nv[0]) {                                                                                      \
+        float* tp = tape.planes + (int64_t)4 * s * tape.ld + base;                                      \
+        const bool tv = whole || (vec != 0 && nv[0] == N);                                              \
+        st_(tp, idx[0], r[0].d.x, tv, nv[0]);                                                           \
+        st_(tp + tape.ld, idx[0], r[0].d.y, tv, nv[0]);                                                 \
+        st_(tp + 2 * tape.ld, idx[0], r[0].d.z, tv, nv[0]);                                             \
+        st_(tp + 3 * tape.ld, idx[0], sel(hit, t_raw, splat<T>(-1.0f)), tv, nv[0]);                     \
+      }                                                                                                 \
+    }                                                                                                   \
+    interact<CFG>(S, f, t_raw, hit, r[0], tse, idx[0], nv[0]);                                          \
+  }
+        RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+#undef RTT_CALL
+      } else {
 #define RTT_CALL(CFG)                                              \
   _Pragma("unroll") for (int g = 0; g < G; ++g) visit_seq<CFG>(S, r[g], tse, idx[g], nv[g])
-      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+        RTT_DISPATCH(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
+      }
+    }
+    if constexpr (TAPE) {
+      const int64_t first = base + (int64_t)(threadIdx.x & ~63u) * N;  // first ray of this wavefront's group
+      if ((threadIdx.x & 63u) == 0u && first < io.n) tape.groups[first / kTapeGroup] = group_hits;
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -3029,47 +3072,72 @@ int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, bool compact
   const int64_t per_ray = compact ? kAdjStart + (int64_t)n_surf * kAdjStateCompact : (int64_t)n_surf * kAdjState;
   return (int64_t)kBlock * 4 * ((int64_t)n_acc + per_ray * rays_per_lane);
 }
-constexpr int kAdjCompactSurfaces = 6;       // longest program swept with compact states (the walk is quadratic)
 
 constexpr int kMaxDevices = 64;
-constexpr int kAdjRegSurfaces = 4;           // longest program whose per-surface states the sweep keeps in registers
-constexpr int kAdjRegAcc = 64;               // slot sums of that variant: one lane of a register pair each
-int g_adjoint_state = 0;                     // 0: registers when the program and the slot sums fit, 1: always LDS
+int g_adjoint_state = 0;                     // 0: compact states where they buy a third wavefront per SIMD, 1: full states always
+
+int g_adjoint_rounds = 3;                    // rounds of resident blocks in the grid of the reverse sweep (capped at 2048 blocks)
+
+// Compute units of the current device (256 on an MI355X), asked once per device.
+int compute_units() {
+  static std::atomic<int> known[kMaxDevices];
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+  int n = known[dev].load(std::memory_order_acquire);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  known[dev].store(n, std::memory_order_release);
+  return n;
+}
 
 // Dynamic LDS above 64 KB has to be granted per kernel and per device (each device holds its own copy of the code
 // object): done once for the device that is current, remembered per device and instantiation.
-template <class T, int BS, int NS, bool COMPACT>
+template <class T, int BS, bool COMPACT, bool TAPE>
 int grant_adjoint_lds() {
-  if (NS > 0) return RTT_OK;  // the register variant asks for no dynamic LDS
   static std::atomic<bool> granted[kMaxDevices];
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return RTT_E_LAUNCH;
   if (granted[dev].load(std::memory_order_acquire)) return RTT_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS, NS, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS, COMPACT, TAPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           kLdsBytes) != hipSuccess)
     return RTT_E_LAUNCH;
   granted[dev].store(true, std::memory_order_release);
   return RTT_OK;
 }
 
-template <class T, int BS, int NS, bool COMPACT = false>
+template <class T, int BS, bool COMPACT = false, bool TAPE = false>
 int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
                    int vec, int64_t lds, int blocks, hipStream_t st) {
-  const int rc = grant_adjoint_lds<T, BS, NS, COMPACT>();
+  const int rc = grant_adjoint_lds<T, BS, COMPACT, TAPE>();
   if (rc != RTT_OK) return rc;
   if (blocks == 0) return RTT_OK;  // a call without rays only prepares the device
-  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS, NS, COMPACT>), dim3(blocks), dim3(BS), (size_t)(NS > 0 ? 0 : lds), st, io, prog_dev, n_surf,
-                     ops, am, a, vec);
+  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS, COMPACT, TAPE>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am,
+                     a, vec);
   return launch_status();
 }
 
-// Shared body of the two adjoint entry points: `partials` is the block-sum scratch ([kAdjMaxBlocks][n_acc] doubles).
+// A tape in memory: 4 n_surf planes of ld floats (ld = n rounded up to an even number, so that every plane of a 256-byte
+// aligned tape is 8-byte aligned), then one 64-bit surface mask per group of kTapeGroup rays.
+struct TapeLayout {
+  int64_t ld, groups, bytes;
+};
+TapeLayout tape_layout(int64_t n, int n_surf) {
+  TapeLayout t;
+  t.ld = (n + 1) & ~(int64_t)1;
+  t.groups = (n + kTapeGroup - 1) / kTapeGroup;
+  t.bytes = (int64_t)16 * n_surf * t.ld + 8 * t.groups;
+  return t;
+}
+
+// Shared body of the adjoint entry points: `partials` is the block-sum scratch ([kAdjMaxBlocks][n_acc] doubles).  With a
+// tape (and spot_w in spot mode) there is no forward sweep and dir_in / inten_in are not read.
 int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, int64_t n,
                       const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask,
                       const float* adj_pos, const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld,
                       int spot_slot, int spot_centroid, double cx, double cy, double wsum, const double* spot_mom, float* ray_adj,
-                      int64_t ld_ray, double* slot_adj, double* partials, int64_t partial_rows, hipStream_t st) {
-  if (!pos_in || !dir_in || !inten_in || !prog_dev || !prog_host) return RTT_E_NULL;
+                      int64_t ld_ray, double* slot_adj, double* partials, int64_t partial_rows, hipStream_t st,
+                      const void* tape = nullptr, int64_t tape_bytes = 0, const float* spot_w = nullptr) {
+  if (!pos_in || (!tape && (!dir_in || !inten_in)) || !prog_dev || !prog_host) return RTT_E_NULL;
   if (n < 0 || ld_in < n) return RTT_E_SIZE;
   if ((adj_pos || adj_dir) && ld_adj < n) return RTT_E_SIZE;
   if (adj_sens && sens_ld < n) return RTT_E_SIZE;
@@ -3093,33 +3161,47 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
   if (n_acc > 0 && (!slot_adj || !partials)) return RTT_E_NULL;
   // short programs with few slot sums keep everything in registers (two rays per lane unless one is forced); the
   // others keep the per-surface states and per-lane sums in LDS, which then sets rays per lane and occupancy
-  // g_adjoint_state: 0 = compact LDS states for short programs when they buy a third wavefront per SIMD, 1 = full LDS
-  // states always, 2 = registers for programs of at most four surfaces
-  const bool regs = g_adjoint_state == 2 && g_adjoint_lane != 1 && n_surf <= kAdjRegSurfaces && n_acc <= kAdjRegAcc;
-  const bool compact = !regs && g_adjoint_state == 0 && g_adjoint_lane != 1 && n_surf <= kAdjCompactSurfaces &&
-                       adjoint_lds_bytes(n_surf, n_acc, 2, true) <= kLdsBytes / 3 && adjoint_lds_bytes(n_surf, n_acc, 2) > kLdsBytes / 3;
-  int lanes = g_adjoint_lane;
-  if (lanes == 0) lanes = regs || compact || adjoint_lds_bytes(n_surf, n_acc, 2) <= kLdsBytes / 2 ? 2 : 1;
-  if (!regs && adjoint_lds_bytes(n_surf, n_acc, lanes, compact) > kLdsBytes) return RTT_E_SIZE;
+  // compact states for short programs when they buy a third wavefront per SIMD (unless tuned off)
+  bool compact = g_adjoint_state == 0 && g_adjoint_lane != 1 && n_surf <= kAdjCompactSurfaces &&
+                 adjoint_lds_bytes(n_surf, n_acc, 2, true) <= kLdsBytes / 3 && adjoint_lds_bytes(n_surf, n_acc, 2) > kLdsBytes / 3;
+  TapeLayout tl = {};
+  if (tape) {  // a tape is swept with compact states, two rays per lane, whatever the tuning says
+    if (n_surf > kAdjCompactSurfaces || adjoint_lds_bytes(n_surf, n_acc, 2, true) > kLdsBytes) return RTT_E_SIZE;
+    tl = tape_layout(n, n_surf);
+    if (tape_bytes < tl.bytes) return RTT_E_SIZE;
+    if ((reinterpret_cast<uintptr_t>(tape) & 255u) || misaligned(spot_w)) return RTT_E_ALIGN;
+    if (spot_slot >= 0 && !spot_w) return RTT_E_NULL;
+    compact = true;
+  }
+  int lanes = tape ? 2 : g_adjoint_lane;
+  if (lanes == 0) lanes = compact || adjoint_lds_bytes(n_surf, n_acc, 2) <= kLdsBytes / 2 ? 2 : 1;
+  if (adjoint_lds_bytes(n_surf, n_acc, lanes, compact) > kLdsBytes) return RTT_E_SIZE;
   const int64_t lds = adjoint_lds_bytes(n_surf, n_acc, lanes, compact);
   const int64_t tile = (int64_t)kBlock * lanes;
   int64_t blocks = (n + tile - 1) / tile;  // none for a call without rays, which still prepares the current device
-  if (blocks > kAdjMaxBlocks) blocks = kAdjMaxBlocks;
+  // About three rounds of resident blocks (registers allow 3 blocks per unit with compact states, else 2; LDS may allow
+  // fewer), walked over the tiles by grid stride.  Measured at 32 Mi rays: one round of blocks that all start together
+  // stays in lock step (every wavefront loads, then every wavefront computes) and is 2 % slower than three rounds.
+  int64_t resident = (int64_t)compute_units() * g_adjoint_rounds * std::min<int64_t>(compact ? 3 : 2, kLdsBytes / std::max<int64_t>(lds, 1));
+  if (resident > kAdjMaxBlocks) resident = kAdjMaxBlocks;
+  if (blocks > resident) blocks = resident;
   if (n_acc > 0 && blocks > partial_rows) return RTT_E_SIZE;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, nullptr, nullptr, nullptr, 0, n};
   AdjointIO a = {adj_pos, adj_dir, ld_adj, adj_sens, sens_ld, spot_slot, spot_centroid, (float)cx, (float)cy,
-                 (spot_slot >= 0 && !spot_mom) ? (float)(1.0 / wsum) : 0.0f, spot_mom, ray_adj, ld_ray, partials, n_acc};
+                 (spot_slot >= 0 && !spot_mom) ? (float)(1.0 / wsum) : 0.0f, spot_mom, ray_adj, ld_ray, partials, n_acc,
+                 (const float*)tape, tl.ld, tape ? (const uint64_t*)((const char*)tape + (int64_t)16 * n_surf * tl.ld) : nullptr,
+                 spot_w};
   const Ops ops = make_ops(prog_host, n_surf);
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) && aligned8(adj_pos) &&
-                  aligned8(adj_dir) && aligned8(adj_sens);
-  if (regs)
-    rc = launch_adjoint<f2, kBlock, kAdjRegSurfaces>(io, prog_dev, n_surf, ops, am, a, vec, 0, (int)blocks, st);
+                  aligned8(adj_dir) && aligned8(adj_sens) && aligned8(spot_w);
+  if (tape)
+    rc = launch_adjoint<f2, kBlock, true, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
   else if (compact)
-    rc = launch_adjoint<f2, kBlock, 0, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
+    rc = launch_adjoint<f2, kBlock, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
   else
-    rc = lanes == 2 ? launch_adjoint<f2, kBlock, 0>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
-                    : launch_adjoint<float, kBlock, 0>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+    rc = lanes == 2 ? launch_adjoint<f2, kBlock>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                    : launch_adjoint<float, kBlock>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
   if (rc != RTT_OK || n_acc == 0) return rc;
   if (n == 0) return hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
   hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, (int64_t)n_acc, (int64_t)1, slot_adj);
@@ -3192,6 +3274,85 @@ int rtt_trace_seq_adjoint_f32(const float* pos_in, const float* dir_in, const fl
   return trace_seq_adjoint(pos_in, dir_in, inten_in, ld_in, n, prog_dev, prog_host, n_surf, slot_mask, adj_pos, adj_dir, ld_adj,
                            adj_sens, sens_ld, spot_slot, spot_centroid, cx, cy, wsum, spot_mom, ray_adj, ld_ray, slot_adj,
                            (double*)workspace, rows, (hipStream_t)stream);
+}
+
+int64_t rtt_trace_seq_tape_bytes(int64_t n, int n_surf) {
+  if (n < 0 || n_surf < 1 || n_surf > RTT_MAX_SURFACES) return 0;
+  return tape_layout(n, n_surf).bytes;
+}
+
+int rtt_trace_seq_adjoint_tape_max_slots(int n_surf) {
+  if (n_surf < 1 || n_surf > kAdjCompactSurfaces) return 0;
+  const int64_t room = (kLdsBytes - adjoint_lds_bytes(n_surf, 0, 2, true)) / (kBlock * 4);
+  return room < 0 ? 0 : (room > kAdjMaxAcc ? kAdjMaxAcc : (int)room);
+}
+
+int rtt_trace_seq_tape_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, float* pos_out,
+                           float* dir_out, float* inten_out, int64_t ld_out, int64_t n, const RttSurface* prog_dev,
+                           const RttSurface* prog_host, int n_surf, float* sens_hit, float* sens_w, uint8_t* sens_mask,
+                           int64_t sens_ld, int mom_slot, double* mom, void* workspace, int64_t workspace_bytes, void* tape,
+                           int64_t tape_bytes, void* stream) {
+  const bool no_rays_out = !pos_out && !dir_out && !inten_out;
+  if (!pos_in || !dir_in || !inten_in || (!no_rays_out && (!pos_out || !dir_out || !inten_out)) || !prog_dev || !prog_host || !tape)
+    return RTT_E_NULL;
+  if (no_rays_out) ld_out = ld_in;
+  if (n < 0 || ld_in < n || ld_out < n) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out) || misaligned(sens_hit) || misaligned(sens_w) || (reinterpret_cast<uintptr_t>(mom) & 7u) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 7u) || (reinterpret_cast<uintptr_t>(tape) & 255u))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int n_slots = 0;
+  int rc = check_program(prog_host, n_surf, &any_sensor, &n_slots);
+  if (rc != RTT_OK) return rc;
+  if (any_sensor && (!sens_hit || !sens_w || !sens_mask)) return RTT_E_NULL;
+  if (any_sensor && sens_ld < n) return RTT_E_SIZE;
+  const bool moments = mom_slot >= 0;
+  if (moments && (!mom || !workspace)) return RTT_E_NULL;
+  if (moments && (mom_slot >= n_slots || workspace_bytes < (int64_t)sizeof(double) * 3 * kMomBins)) return RTT_E_SIZE;
+  if (!moments && no_rays_out) return RTT_E_NULL;  // only the launch that sums moments can leave the rays unwritten
+  const TapeLayout tl = tape_layout(n, n_surf);
+  if (tape_bytes < tl.bytes) return RTT_E_SIZE;
+  const hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return !moments || hipMemsetAsync(mom, 0, 3 * sizeof(double), st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
+  if (moments && hipMemsetAsync(workspace, 0, sizeof(double) * 3 * kMomBins, st) != hipSuccess) return RTT_E_LAUNCH;
+  RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+  SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
+  se.mom_slot = mom_slot;
+  const TapeIO tp = {(float*)tape, tl.ld, (uint64_t*)((char*)tape + (int64_t)16 * n_surf * tl.ld)};
+  const Ops ops = make_ops(prog_host, n_surf);
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) &&
+                  aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+  // (the grid is not capped: a block's wavefronts are the groups of its one tile)
+  const dim3 grid((unsigned)((n + 2 * kBlock - 1) / (2 * kBlock)));
+  if (moments) {
+    hipLaunchKernelGGL((k_trace_seq<f2, 1, false, true, false, true>), grid, dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec,
+                       (double*)workspace, GenIO{}, tp);
+    if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
+    hipLaunchKernelGGL(k_sum_partials, dim3(3), dim3(kBlock), 0, st, (const double*)workspace, kMomBins, (int64_t)1, (int64_t)kMomBins,
+                       mom);
+  } else {
+    hipLaunchKernelGGL((k_trace_seq<f2, 1, false, false, false, true>), grid, dim3(kBlock), 0, st, io, prog_dev, n_surf, ops, se, vec,
+                       (double*)nullptr, GenIO{}, tp);
+  }
+  return launch_status();
+}
+
+int rtt_trace_seq_adjoint_tape_f32(const float* pos_in, int64_t ld_in, int64_t n, const RttSurface* prog_dev,
+                                   const RttSurface* prog_host, int n_surf, const uint32_t* slot_mask, const float* adj_pos,
+                                   const float* adj_dir, int64_t ld_adj, const float* adj_sens, int64_t sens_ld, int spot_slot,
+                                   int spot_centroid, double cx, double cy, double wsum, const double* spot_mom, const float* spot_w,
+                                   float* ray_adj, int64_t ld_ray, double* slot_adj, void* workspace, int64_t workspace_bytes,
+                                   const void* tape, int64_t tape_bytes, void* stream) {
+  if (!tape) return RTT_E_NULL;
+  int n_acc = 0;
+  if (slot_mask && n_surf >= 1 && n_surf <= RTT_MAX_SURFACES)
+    for (int s = 0; s < n_surf; ++s) n_acc += __builtin_popcount(slot_mask[s]);
+  const int64_t rows = n_acc > 0 ? workspace_bytes / ((int64_t)sizeof(double) * n_acc) : 0;
+  return trace_seq_adjoint(pos_in, nullptr, nullptr, ld_in, n, prog_dev, prog_host, n_surf, slot_mask, adj_pos, adj_dir, ld_adj,
+                           adj_sens, sens_ld, spot_slot, spot_centroid, cx, cy, wsum, spot_mom, ray_adj, ld_ray, slot_adj,
+                           (double*)workspace, rows, (hipStream_t)stream, tape, tape_bytes, spot_w);
 }
 
 int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n, const RttSurface* prog_dev,
@@ -3611,7 +3772,11 @@ int rtt_tune(int key, int value) {
     g_moments_threads = value;
     return RTT_OK;
   }
-  if (key == 7 && value >= 0 && value <= 2) {
+  if (key == 9 && value >= 1 && value <= 8) {
+    g_adjoint_rounds = value;
+    return RTT_OK;
+  }
+  if (key == 7 && (value == 0 || value == 1)) {
     g_adjoint_state = value;
     return RTT_OK;
   }
@@ -3619,5 +3784,21 @@ int rtt_tune(int key, int value) {
 }
 
 int rtt_surface_record_bytes(void) { return (int)sizeof(RttSurface); }
+
+#if RTT_PHASE_TIMERS
+// Profiling build only (`make prof`): the phase clocks of the reverse sweep summed over all wavefronts since the last
+// reset; out[k] for k < n.
+int rtt_debug_phases(unsigned long long* out, int n, int reset) {
+  unsigned long long host[kPhases] = {};
+  if (hipDeviceSynchronize() != hipSuccess) return RTT_E_LAUNCH;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase), sizeof(host)) != hipSuccess) return RTT_E_LAUNCH;
+  for (int k = 0; k < n && k < kPhases; ++k) out[k] = host[k];
+  if (reset) {
+    const unsigned long long zero[kPhases] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero)) != hipSuccess) return RTT_E_LAUNCH;
+  }
+  return RTT_OK;
+}
+#endif
 
 }  // extern "C"

@@ -151,12 +151,33 @@ def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
     return rec
 
 
-def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=None, store: bool = True):
+class Tape:
+    """What a trace kept for its reverse sweep (`rtt_trace_seq_tape_f32`): an opaque device buffer, valid for the rays
+    and the program of that trace."""
+    __slots__ = ("buf", "n", "n_surf")
+
+    def __init__(self, n, n_surf, device):
+        self.n, self.n_surf = n, n_surf
+        self.buf = torch.empty(int(N.lib().rtt_trace_seq_tape_bytes(n, n_surf)), dtype=torch.uint8, device=device)
+
+
+def tape_slots(n_surf: int) -> int:
+    """Slot sums one reverse sweep from a tape can return for a program of `n_surf` surfaces; 0 = such a program is not
+    swept from a tape."""
+    return int(N.lib().rtt_trace_seq_adjoint_tape_max_slots(int(n_surf))) if 1 <= n_surf <= P.MAX_SURFACES else 0
+
+
+def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=None, store: bool = True, tape: bool = False):
     """SequentialScene.simulate on the device.  Writes into `out` (default: in place into `rays`).
     Returns (sens_hit [K,3,N], sens_w [K,N], sens_mask [K,N] uint8) or (None, None, None).
     `moments` = (sensor slot, float64 device tensor of at least 3 entries): the same launch also leaves the first
     spot-size moments (sum w, sum w x, sum w y over the lit hits of that slot) in the tensor's first three entries.
-    With `store=False` (moments only) the traced rays are not written: `rays` keeps its planes and `out` is ignored."""
+    With `store=False` (moments only) the traced rays are not written: `rays` keeps its planes and `out` is ignored.
+    With `tape` the launch also keeps what the reverse sweep needs and a fourth value is returned, the `Tape` (None for
+    an empty bundle or program); the result must then go out of place (`out` is not `rays`), since the sweep reads the
+    input positions."""
+    if tape:
+        return _trace_sequential_tape(rays, prog, out, moments, store)
     n = _check_rays(rays)
     if not store:
         if moments is None:
@@ -199,6 +220,45 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=Non
     if code:
         N.check(code, "rtt_trace_seq_f32")
     return sens_hit, sens_w, sens_mask
+
+
+def _trace_sequential_tape(rays, prog, out, moments, store):
+    n = _check_rays(rays)
+    if not store:
+        if moments is None:
+            raise ValueError("only the trace that sums moments can leave the traced rays unwritten")
+        out = None
+    else:
+        if out is None or out is rays or out._pos is rays._pos:
+            raise ValueError("a trace that keeps a tape writes its result out of place: the reverse sweep reads the input positions")
+        if _check_rays(out) != n:
+            raise ValueError("`out` must hold the same number of rays")
+    dev = rays.device
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev, zero_mask=False)
+    if n == 0 or prog.shape[0] == 0:
+        if out is not None:
+            out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
+        if moments is not None:
+            moments[1][:3] = 0.0
+        return sens_hit, sens_w, sens_mask, None
+    dp = N.DeviceProgram.upload(prog, dev)
+    lib = N.lib()
+    kept = Tape(n, dp.n, dev)
+    slot, mom, ws, ws_bytes = -1, None, None, 0
+    if moments is not None:
+        slot, mom = moments
+        if mom.dtype != torch.float64 or mom.numel() < 3 or not mom.is_contiguous() or mom.device != dev:
+            raise ValueError("`moments` needs a contiguous float64 tensor of at least 3 entries on the rays' device")
+        ws_bytes = int(lib.rtt_trace_seq_moments_workspace_bytes(n))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        code = lib.rtt_trace_seq_tape_f32(
+            N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+            N.ptr(out._pos) if store else None, N.ptr(out._dir) if store else None, N.ptr(out.intensity) if store else None, n, n,
+            N.ptr(dp.dev), dp.host_ptr, dp.n, N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n, int(slot), N.ptr(mom),
+            N.ptr(ws), ws_bytes, N.ptr(kept.buf), kept.buf.numel(), N.stream_handle(dev))
+    N.check(code, "rtt_trace_seq_tape_f32")
+    return sens_hit, sens_w, sens_mask, kept
 
 
 def trace_sequential_history(rays: Rays, prog: np.ndarray):

@@ -149,9 +149,17 @@ class SpotSizeLoss(Goal):
         else:
             # The loss reads the sensor, not the traced bundle: the trace leaves the rays unwritten (28 B per ray) and
             # `scene.rays` gets them from a repeat of the trace should anybody look at them.
-            hit, w, mask = K.trace_sequential(src, prog, moments=(k, mom), store=False)
+            kept = None
+            if AG.keeps_tape(prog):   # the trace also keeps what the reverse sweep needs (no second trace in the backward)
+                hit, w, mask, kept = K.trace_sequential(src, prog, moments=(k, mom), store=False, tape=True)
+            else:
+                hit, w, mask = K.trace_sequential(src, prog, moments=(k, mom), store=False)
             scene._deliver_sensor_records(prog, src, hit, w, mask)
             SampledRays.defer(rays, PendingTrace(src, prog, src.id, src.wavelength))
+            if kept is not None:
+                return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k], kept), target=tgt,
+                                          group=getattr(scene, "grad_group", None), params=scene._element_params()[1],
+                                          table_cache=(scene.__dict__, scene._prog_cache[0]), mom=mom)
         # the host work of the backward's set-up (parameter list, slot Jacobians) runs while the device traces;
         # "nothing lit reached the sensor" (optim/goals.py:165-167) is read off the first moment, W = 0
         return AG.fused_spot_loss(list(scene.elements), src, prog, k, (hit[k], w[k], mask[k]), target=tgt,

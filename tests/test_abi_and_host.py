@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in rtt_hip.h but not exported"
     assert set(names) == set(_native.EXPORTS)
-    assert lib.rtt_abi_version() == 5
+    assert lib.rtt_abi_version() == 6
     assert lib.rtt_surface_record_bytes() == 256 == P.RECORD_BYTES
 
 
