@@ -263,9 +263,9 @@ int rtt_ray_cast_f32(const float* pos, const float* dir, int64_t ld, int64_t n,
 
 /* ---- one non-sequential bounce: Scene.step (scene/base.py:180-235) ----------------------------
  * ray_cast + winner dispatch + scatter_update for rays with a hit and intensity > 0.
- * winner (nullable) receives the ray_cast result.  Sensor outputs as in rtt_trace_seq_f32, except that a bounce
- * writes the mask entry only of rays that went to a sensor: the call clears the mask planes first (with a host copy
- * of the program; without one the caller passes them zeroed). */
+ * winner (nullable) receives the ray_cast result.  Sensor outputs as in rtt_trace_seq_f32; a bounce writes a 1 only for
+ * rays that went to a sensor, so the kernel first clears the mask entries of all rays on all slots (with a host copy of
+ * the program, from which it knows the slots; without one the caller passes the mask planes zeroed). */
 int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
                          float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
                          const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf,
@@ -437,6 +437,30 @@ int rtt_sample_trace_seq_f32(const RttSource* src, float* pos_out, float* dir_ou
  * out is [256][3] float64 in device memory (zeroed by the caller before each pass), centers [256][2] float64. */
 int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const uint8_t* mask, const int8_t* id,
                         int64_t n, int pass, const double* centers, double norm_ord, double* out, void* stream);
+
+/* ---- prepared launches: the stepping loops of the reference (benchmarks/sim_benchmark.py:107-124: scene.step() twenty
+ * times on the same rays; scene/sequential.py:12-36 called per optimisation step on the same planes) repeat one launch
+ * with the same arguments.  rtt_prepare_* validates the arguments of rtt_trace_seq_f32 / rtt_step_nearest_f32 once
+ * (program checks, opcode and culling tables, access width, grid) and returns an opaque handle in host memory (the one
+ * thing this library allocates, freed by rtt_release_prepared); rtt_launch_prepared enqueues the launch.  The sensor
+ * record of a launch is ONE device allocation of rtt_sensor_record_bytes(slots, sens_ld) bytes that the caller passes per
+ * launch (NULL for a program without sensor surfaces): hit planes [slots][3][sens_ld] float, then intensities
+ * [slots][sens_ld] float, then masks [slots][sens_ld] bytes, as rtt_trace_seq_f32 / rtt_step_nearest_f32 fill their three
+ * buffers (the bounce clears the masks first).  The ray planes, the device program and sens_ld are bound by the handle:
+ * the caller keeps them alive and prepares again when any of them, or an rtt_tune setting, changes (RTT_E_KIND: stale).
+ * A handle may be launched from one thread at a time.  n >= 1; prog_host is required. */
+typedef struct RttLaunch RttLaunch;
+int rtt_prepare_trace_seq_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                              float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                              const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int64_t sens_ld,
+                              RttLaunch** out);
+int rtt_prepare_step_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
+                                 float* pos_out, float* dir_out, float* inten_out, int64_t ld_out, int64_t n,
+                                 const RttSurface* prog_dev, const RttSurface* prog_host, int n_surf, int64_t sens_ld,
+                                 RttLaunch** out);
+int rtt_launch_prepared(const RttLaunch* launch, void* sens_base, void* stream);
+void rtt_release_prepared(RttLaunch* launch);
+int64_t rtt_sensor_record_bytes(int n_slots, int64_t sens_ld);
 
 /* Launch tuning, process-wide, optional.  key 0: rays carried per lane by rtt_trace_seq_f32 (1, 2 or 4);
  * key 1: cap on the number of 256-thread blocks per launch (the remainder is grid-stride);

@@ -65,7 +65,9 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES) + ("rtt_strerror", "rtt_abi_version", "rtt_surface_record_bytes", "rtt_tune",
                                 "rtt_trace_seq_adjoint_max_slots", "rtt_trace_seq_adjoint_workspace_bytes",
                                 "rtt_trace_seq_moments_workspace_bytes", "rtt_simulate_nearest_staged_workspace_bytes",
-                                "rtt_trace_seq_tape_bytes", "rtt_trace_seq_adjoint_tape_max_slots")
+                                "rtt_trace_seq_tape_bytes", "rtt_trace_seq_adjoint_tape_max_slots",
+                                "rtt_prepare_trace_seq_f32", "rtt_prepare_step_nearest_f32", "rtt_launch_prepared",
+                                "rtt_release_prepared", "rtt_sensor_record_bytes")
 
 
 class RttSource(ctypes.Structure):
@@ -115,6 +117,16 @@ def lib():
     L.rtt_trace_seq_tape_bytes.restype = _i64
     L.rtt_trace_seq_adjoint_tape_max_slots.argtypes = [_int]
     L.rtt_trace_seq_adjoint_tape_max_slots.restype = _int
+    L.rtt_prepare_trace_seq_f32.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _i64, ctypes.POINTER(_vp)]
+    L.rtt_prepare_trace_seq_f32.restype = _int
+    L.rtt_prepare_step_nearest_f32.argtypes = L.rtt_prepare_trace_seq_f32.argtypes
+    L.rtt_prepare_step_nearest_f32.restype = _int
+    L.rtt_launch_prepared.argtypes = [_vp, _vp, _vp]
+    L.rtt_launch_prepared.restype = _int
+    L.rtt_release_prepared.argtypes = [_vp]
+    L.rtt_release_prepared.restype = None
+    L.rtt_sensor_record_bytes.argtypes = [_int, _i64]
+    L.rtt_sensor_record_bytes.restype = _i64
     if L.rtt_surface_record_bytes() != P.RECORD_BYTES:
         raise NativeLibraryError("RttSurface size mismatch between librtt_hip.so and program.py")
     _lib = L
@@ -144,6 +156,26 @@ def stream_handle(device):
         device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
     return torch._C._cuda_getCurrentRawStream(index)
+
+
+class PreparedLaunch:
+    """Handle of `rtt_prepare_*`: one launch with its arguments validated and bound (ray planes, device program, sensor
+    leading dimension).  `launch(sens_base, stream)` enqueues it; the handle is released with the object."""
+    __slots__ = ("handle", "_launch", "_release")
+
+    def __init__(self, prepare, *args):
+        L = lib()
+        out = _vp()
+        check(prepare(*args, ctypes.byref(out)), "rtt_prepare")
+        self.handle, self._launch, self._release = out.value, L.rtt_launch_prepared, L.rtt_release_prepared
+
+    def launch(self, sens_base, stream):
+        return self._launch(self.handle, sens_base, stream)
+
+    def __del__(self):
+        h, self.handle = self.handle, None
+        if h:
+            self._release(h)
 
 
 class DeviceProgram:

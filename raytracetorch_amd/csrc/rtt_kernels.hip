@@ -29,6 +29,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <new>
 #include <type_traits>
 
 #include "rtt_hip.h"
@@ -1126,6 +1128,9 @@ struct SensorIO {
   int32_t mom_slot;
   // append mode when the launch holds a compacted subset of the call's rays: the keys of the lane's rays
   int32_t use_lane_key, lane_key[2];
+  // one bounce with dense slots: a ray writes its mask entry only on the sensor it goes to, so every lane first clears
+  // the entries of its rays on the first zero_slots slots (0: the caller cleared the planes)
+  int32_t zero_slots;
 };
 
 DI float hsum(float v) { return v; }
@@ -1971,6 +1976,18 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
       seb.use_lane_key = 1;
 #pragma unroll
       for (int k = 0; k < N; ++k) seb.lane_key[k] = orig[k];
+    }
+    if (SINGLE && live) {
+      for (int slot = 0; slot < se.zero_slots; ++slot) {
+        uint8_t* m = se.mask + (int64_t)slot * se.ld + i;
+        if (vec != 0 && nv == 2) {
+          *reinterpret_cast<uint16_t*>(m) = 0;   // (ld and the ray index are even: the pair is 2-byte aligned)
+        } else {
+#pragma unroll
+          for (int k = 0; k < N; ++k)
+            if (k < nv) m[k] = 0;
+        }
+      }
     }
     const int max_bounces = SINGLE ? 1 : max_bounces_;  // SINGLE: Scene.step, the loop folds away
     for (int b = 0; b < max_bounces; ++b) {
@@ -3109,8 +3126,8 @@ template <class T, int BS, bool COMPACT = false, bool TAPE = false>
 int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
                    int vec, int64_t lds, int blocks, hipStream_t st) {
   const int rc = grant_adjoint_lds<T, BS, COMPACT, TAPE>();
+  if (blocks == 0) return RTT_OK;  // a call without rays only prepares the current device, if there is one
   if (rc != RTT_OK) return rc;
-  if (blocks == 0) return RTT_OK;  // a call without rays only prepares the device
   hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS, COMPACT, TAPE>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am,
                      a, vec);
   return launch_status();
@@ -3387,15 +3404,15 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   if (any_sensor && (!sens_hit || !sens_w || !sens_mask)) return RTT_E_NULL;
   if (any_sensor && sens_ld < n) return RTT_E_SIZE;
   if (n == 0) return RTT_OK;
-  // a bounce writes the mask entry only of rays that went to a sensor: the planes start from zero
-  if (prog_host && n_slots > 0 &&
-      hipMemsetAsync(sens_mask, 0, (size_t)n_slots * (size_t)sens_ld, (hipStream_t)stream) != hipSuccess)
-    return RTT_E_LAUNCH;
   RayIO io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   SensorIO se = {sens_hit, sens_w, sens_mask, sens_ld};
+  // a bounce writes the mask entry only of rays that went to a sensor: every lane clears the entries of its rays first
+  // (the kernel knows how many slots there are from the host copy of the program)
+  se.zero_slots = prog_host ? n_slots : 0;
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
-                  aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+                  aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out) &&
+                  (sens_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(sens_mask) & 1u) == 0;
   hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
                      n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), 1, winner, (int32_t*)nullptr, se, vec);
   return launch_status();
@@ -3725,12 +3742,123 @@ int rtt_sample_bundle_f32(const RttSource* src, float* pos, float* dir, int64_t 
   return launch_status();
 }
 
+// ---- prepared launches -----------------------------------------------------------------------------------------------
+// Everything a launch derives from its arguments that does not change from call to call (validated program, opcode
+// and culling tables, access width, grid, kernel variant), kept in host memory behind an opaque handle: a stepping loop
+// then pays a three-argument call, one memset (bounce) and the launch.
+}  // extern "C"
+
+namespace {
+int g_tune_epoch = 0;  // bumped by rtt_tune: a handle prepared under other settings is stale
+}
+
+struct RttLaunch {
+  int kind;  // 0: sequential trace, 1: one nearest-hit bounce
+  int epoch;
+  RayIO io;
+  const RttSurface* prog_dev;
+  int n_surf, vec, n_slots, variant;
+  int64_t sens_ld;
+  Ops ops;
+  Cull cull;
+  unsigned grid;
+};
+
+extern "C" {
+
+int rtt_prepare_trace_seq_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, float* pos_out,
+                              float* dir_out, float* inten_out, int64_t ld_out, int64_t n, const RttSurface* prog_dev,
+                              const RttSurface* prog_host, int n_surf, int64_t sens_ld, RttLaunch** out) {
+  if (!out) return RTT_E_NULL;
+  *out = nullptr;
+  if (!pos_in || !dir_in || !inten_in || !pos_out || !dir_out || !inten_out || !prog_dev || !prog_host) return RTT_E_NULL;
+  if (n < 1 || ld_in < n || ld_out < n) return RTT_E_SIZE;
+  if (misaligned(pos_in) || misaligned(dir_in) || misaligned(inten_in) || misaligned(pos_out) || misaligned(dir_out) ||
+      misaligned(inten_out))
+    return RTT_E_ALIGN;
+  bool any_sensor;
+  int n_slots = 0;
+  const int rc = check_program(prog_host, n_surf, &any_sensor, &n_slots);
+  if (rc != RTT_OK) return rc;
+  if (any_sensor && sens_ld < n) return RTT_E_SIZE;
+  RttLaunch* h = new (std::nothrow) RttLaunch();
+  if (!h) return RTT_E_LAUNCH;
+  h->kind = 0;
+  h->epoch = g_tune_epoch;
+  h->io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
+  h->prog_dev = prog_dev;
+  h->n_surf = n_surf;
+  h->n_slots = any_sensor ? n_slots : 0;
+  h->sens_ld = sens_ld;
+  h->ops = make_ops(prog_host, n_surf);
+  auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
+  h->vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) && aligned8(inten_in) &&
+           aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
+  h->variant = g_rays_per_lane == 1 ? 1 : (g_rays_per_lane == 4 ? 4 : (g_program_in_lds ? 3 : 2));
+  h->grid = (unsigned)grid_for(n, h->variant == 1 ? 1 : (h->variant == 4 ? 4 : 2));
+  *out = h;
+  return RTT_OK;
+}
+
+int rtt_prepare_step_nearest_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in, float* pos_out,
+                                 float* dir_out, float* inten_out, int64_t ld_out, int64_t n, const RttSurface* prog_dev,
+                                 const RttSurface* prog_host, int n_surf, int64_t sens_ld, RttLaunch** out) {
+  const int rc = rtt_prepare_trace_seq_f32(pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n, prog_dev,
+                                           prog_host, n_surf, sens_ld, out);
+  if (rc != RTT_OK) return rc;
+  RttLaunch* h = *out;
+  h->kind = 1;
+  h->cull = make_cull(prog_host, n_surf);
+  h->variant = 2;
+  h->grid = (unsigned)grid_for(n, 2);
+  return RTT_OK;
+}
+
+int rtt_launch_prepared(const RttLaunch* h, void* sens_base, void* stream) {
+  if (!h) return RTT_E_NULL;
+  if (h->epoch != g_tune_epoch) return RTT_E_KIND;  // prepared under other rtt_tune settings: prepare again
+  if (h->n_slots > 0 && !sens_base) return RTT_E_NULL;
+  if (misaligned(sens_base)) return RTT_E_ALIGN;
+  // one allocation holds the record: hit planes [slots][3][ld], intensities [slots][ld], masks [slots][ld] bytes
+  SensorIO se = {};
+  if (h->n_slots > 0) {
+    const int64_t plane = (int64_t)h->n_slots * h->sens_ld;
+    se.hit = (float*)sens_base;
+    se.w = se.hit + 3 * plane;
+    se.mask = (uint8_t*)(se.w + plane);
+    se.ld = h->sens_ld;
+  }
+  const hipStream_t st = (hipStream_t)stream;
+  if (h->kind == 1) {
+    se.zero_slots = h->n_slots;   // the kernel clears the mask entries of its rays before the bounce
+    // (8-byte accesses also need the masks' pairs 2-byte aligned: an odd sens_ld or base falls back to 4-byte accesses)
+    const int vec = h->vec && (h->sens_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(se.mask) & 1u) == 0;
+    hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops, h->cull,
+                       1, (int32_t*)nullptr, (int32_t*)nullptr, se, vec);
+    return launch_status();
+  }
+  switch (h->variant) {
+    case 1: hipLaunchKernelGGL((k_trace_seq<float, 1, false>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops, se, 0); break;
+    case 4: hipLaunchKernelGGL((k_trace_seq<f2, 2, false>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops, se, h->vec); break;
+    case 3: hipLaunchKernelGGL((k_trace_seq<f2, 1, true>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops, se, h->vec); break;
+    default: hipLaunchKernelGGL((k_trace_seq<f2, 1, false>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops, se, h->vec); break;
+  }
+  return launch_status();
+}
+
+void rtt_release_prepared(RttLaunch* h) { delete h; }
+
+int64_t rtt_sensor_record_bytes(int n_slots, int64_t sens_ld) {
+  if (n_slots < 0 || sens_ld < 0) return 0;
+  return ((int64_t)17 * n_slots * sens_ld + 3) & ~(int64_t)3;
+}
+
 const char* rtt_strerror(int code) {
   switch (code) {
     case RTT_OK: return "ok";
     case RTT_E_NULL: return "required pointer is NULL";
     case RTT_E_SIZE: return "size, leading dimension or index out of range";
-    case RTT_E_KIND: return "surface record carries an unknown or inconsistent kind";
+    case RTT_E_KIND: return "surface record carries an unknown or inconsistent kind (or a prepared launch is stale)";
     case RTT_E_LAUNCH: return "kernel launch failed";
     case RTT_E_ALIGN: return "pointer is not sufficiently aligned";
     default: return "unknown error";
@@ -3740,6 +3868,7 @@ const char* rtt_strerror(int code) {
 int rtt_abi_version(void) { return RTT_ABI_VERSION; }
 
 int rtt_tune(int key, int value) {
+  ++g_tune_epoch;
   if (key == 0 && (value == 1 || value == 2 || value == 4)) {
     g_rays_per_lane = value;
     return RTT_OK;

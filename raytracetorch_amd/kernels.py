@@ -122,6 +122,42 @@ class SensorVisit:
         return self.record.n
 
 
+def _prepared(prog, kind, src, dst, n, dev):
+    """The prepared launch of `prog` (a `Program` with facts) on the planes of `src` -> `dst`: found again by the identity
+    of the program and of the six plane tensors (a stepping or optimisation loop passes the same objects every time),
+    prepared on first use.  A few per program are kept; they go with the program.  Returns None for a plain record array."""
+    facts = P.facts_of(prog)
+    if facts is None:
+        return None
+    kept = facts.get(("launches", kind))
+    if kept is None:
+        kept = facts[("launches", kind)] = []
+    a, b, c, d, e, f = src._pos, src._dir, src.intensity, dst._pos, dst._dir, dst.intensity
+    for entry in kept:
+        r = entry[0]
+        if r[0]() is a and r[1]() is b and r[2]() is c and r[3]() is d and r[4]() is e and r[5]() is f and entry[1] == n:
+            return entry[2]
+    dp = N.DeviceProgram.upload(prog, dev)
+    lib = N.lib()
+    with torch.cuda.device(dev):
+        handle = N.PreparedLaunch(lib.rtt_prepare_step_nearest_f32 if kind else lib.rtt_prepare_trace_seq_f32,
+                                  a.data_ptr(), b.data_ptr(), c.data_ptr(), n, d.data_ptr(), e.data_ptr(), f.data_ptr(), n, n,
+                                  dp.dev.data_ptr(), dp.host_ptr, dp.n, n)
+    if len(kept) >= 4:
+        del kept[0]
+    kept.append((tuple(weakref.ref(t) for t in (a, b, c, d, e, f)), n, handle, dp))   # (dp: the device copy the handle reads)
+    return handle
+
+
+def _launch_prepared(handle, rec, dev, what, retry):
+    code = _call_on(dev, handle.launch, rec.buf.data_ptr() if rec is not None else None, N.stream_handle(dev))
+    if code == -3 and retry is not None:   # prepared under other rtt_tune settings: forget the handles and prepare again
+        return retry()
+    if code:
+        N.check(code, what)
+    return rec
+
+
 def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
     """trace_sequential for the plain call (no moments): returns the launch's SensorRecord, or None for a program
     without sensor slots."""
@@ -136,6 +172,14 @@ def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
             out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
         return SensorRecord(k, n, rays.device) if k else None
     dev = rays.device
+    handle = _prepared(prog, 0, rays, out, n, dev)
+    if handle is not None:
+        rec = SensorRecord(k, n, dev) if k else None
+
+        def again():
+            P.facts_of(prog).pop(("launches", 0), None)
+            return _launch_prepared(_prepared(prog, 0, rays, out, n, dev), rec, dev, "rtt_launch_prepared", None)
+        return _launch_prepared(handle, rec, dev, "rtt_launch_prepared", again)
     dp = N.DeviceProgram.upload(prog, dev)
     if k:
         rec = SensorRecord(k, n, dev)
@@ -349,6 +393,14 @@ def step_nearest_record(rays: Rays, prog: np.ndarray):
         if rec is not None:
             rec.views()[2].zero_()
         return rec
+    handle = _prepared(prog, 1, rays, rays, n, dev)
+    if handle is not None:
+        rec = SensorRecord(k, n, dev) if k else None
+
+        def again():
+            P.facts_of(prog).pop(("launches", 1), None)
+            return _launch_prepared(_prepared(prog, 1, rays, rays, n, dev), rec, dev, "rtt_launch_prepared", None)
+        return _launch_prepared(handle, rec, dev, "rtt_launch_prepared", again)
     dp = N.DeviceProgram.upload(prog, dev)
     if k:
         rec = SensorRecord(k, n, dev)

@@ -37,6 +37,18 @@ f32 = np.float32
 
 _host_cache = {}
 
+try:   # host-only C++ helper (raytracetorch_amd/csrc/fastparams.cpp): one call reads what the cache checks below need
+    from . import _fastparams
+    snapshot = _fastparams.snapshot
+except ImportError:   # not built: the same facts, read tensor by tensor
+    def snapshot(params):
+        """(what identifies the storage of every tensor, whether any requires grad, what identifies the state of the
+        tensors outside host memory, the bytes of the host-resident ones)"""
+        host = [q for q in params if q.device.type == "cpu"]
+        return (tuple((q.data_ptr(), q.numel(), q.dtype) for q in params), any(q.requires_grad for q in params),
+                tuple(q._version for q in params if q.device.type != "cpu"),
+                b"".join([q.detach().contiguous().reshape(-1).numpy().tobytes() for q in host]))
+
 
 def host_value(p) -> np.ndarray:
     """float32 host copy of a (possibly device-resident) parameter / tensor / python number."""

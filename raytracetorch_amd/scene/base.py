@@ -17,8 +17,6 @@ from ..elements import Element
 from ..rays import Bundle, Rays
 
 
-_DATA_PTR = operator.methodcaller("data_ptr")
-_VERSION = operator.attrgetter("_version")
 
 
 class Scene(nn.Module):
@@ -104,24 +102,23 @@ class Scene(nn.Module):
             return False
         if rays is not None and (rays._pos.requires_grad or rays._dir.requires_grad):
             return True
-        return any(p.requires_grad for p in self._element_params()[1])
+        params = self._element_params()[1]
+        snap = P.snapshot(params)
+        # `_program()` is what a caller runs next (no user code in between): it takes this pass instead of making its own
+        self.__dict__["_snapshot_ahead"] = (params, snap)
+        return snap[1]
 
     def _program(self):
         """Packed surface program of the current elements; re-packed only when an element list entry or a
-        parameter changed since the last call.  Host-resident parameters are compared by value (numpy views of their
-        storage, so a write through `.data`, which leaves the version counter alone, is seen as well); device-resident
-        ones by storage address and version counter: an in-place write through `p.data` on the device is not seen
-        before `invalidate_program()` — write through `p` under `torch.no_grad()` instead."""
+        parameter changed since the last call.  Host-resident parameters are compared by value (so a write through
+        `.data`, which leaves the version counter alone, is seen as well); device-resident ones by storage address and
+        version counter: an in-place write through `p.data` on the device is not seen before `invalidate_program()` —
+        write through `p` under `torch.no_grad()` instead.  All of it is one pass over the parameters (`P.snapshot`)."""
         els, params, _ = self._element_params()
-        # read by C-level maps (a generator costs as much as a small launch for a few dozen parameters)
-        ptrs = tuple(map(_DATA_PTR, params))
-        views = self.__dict__.get("_param_views")
-        if views is None or views[0] != (els, ptrs):
-            views = self.__dict__["_param_views"] = (
-                (els, ptrs), [q.detach().reshape(-1).numpy() for q in params if q.device.type == "cpu"],
-                [q for q in params if q.device.type != "cpu"])
-        values = b"".join([v.tobytes() for v in views[1]])
-        key = (els, ptrs, values, tuple(map(_VERSION, views[2])))
+        ahead = self.__dict__.pop("_snapshot_ahead", None)
+        # one pass over the parameters in C++ (just made by `_needs_grad`, or made now)
+        storage, _, versions, values = ahead[1] if ahead is not None and ahead[0] is params else P.snapshot(params)
+        key = (els, storage, values, versions)
         cached = getattr(self, "_prog_cache", None)
         if cached is None or cached[0] != key:
             P.prefetch_host(params)
@@ -142,7 +139,7 @@ class Scene(nn.Module):
         """Forget the packed program and every cached host copy of a device-resident parameter of this scene: the next
         trace reads all parameters again (needed only after in-place writes through `p.data` on the device)."""
         self.__dict__.pop("_prog_cache", None)
-        self.__dict__.pop("_param_views", None)
+        self.__dict__.pop("_snapshot_ahead", None)
         for q in self._element_params()[1]:
             P.forget_host_copy(q)
 
