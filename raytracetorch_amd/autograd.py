@@ -340,9 +340,60 @@ def _detached(rays):
     return Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id, rays.wavelength)
 
 
-def trace_sequential_with_grad(elements, rays, prog, group=None):
+SEGMENT_SURFACES = 12   # surfaces per differentiated stretch of a long program (the sweep's LDS then holds 76 slot sums)
+
+
+def one_sweep(prog, n_elements) -> bool:
+    """Whether the program is differentiated in one piece: it fits a launch and (in reverse mode) the sweep's LDS holds
+    a state per surface, or it cannot be cut (a single element)."""
+    n_surf = prog.shape[0]
+    if n_surf > P.MAX_SURFACES:
+        return False
+    return n_elements < 2 or backward_mode() == "tangent" or N.lib().rtt_trace_seq_adjoint_max_slots(n_surf) > 0
+
+
+def _stretches(elements, prog):
+    """A program too long to differentiate in one piece, as stretches of whole elements: [(elements, records)]."""
+    if one_sweep(prog, len(elements)):
+        return None
+    reverse = backward_mode() != "tangent"
+    ids = np.asarray(prog)["element_id"]
+    if int(ids.max()) + 1 != len(elements):
+        raise ValueError("the program was not compiled from these elements")
+    widest = int(np.bincount(ids).max())
+    limit = max(SEGMENT_SURFACES, widest) if reverse else P.MAX_SURFACES
+    if limit > P.MAX_SURFACES:
+        raise ValueError(f"an element of the scene has more than {P.MAX_SURFACES} surfaces")
+    out = []
+    for piece, first, _ in P.split_program(prog, limit):
+        e0, e1 = int(ids[first]), int(ids[first + piece.shape[0] - 1]) + 1
+        out.append((elements[e0:e1], piece))
+    return out
+
+
+def _trace_stretches(stretches, rays, group):
+    """The differentiable trace of a long program: one TraceSeqFn per stretch, each fed the rays the one before it
+    left.  Autograd chains their backward sweeps (the ray adjoint of a stretch is the upstream adjoint of the one in
+    front of it) and adds up what a parameter shared between stretches receives."""
+    from .rays.ray import Rays
+    cur, parts = rays, []
+    for els, piece in stretches:
+        outs = trace_sequential_with_grad(els, cur, piece, group, whole=True)
+        cur = Rays.from_planes(outs[0], outs[1], outs[2], rays.id, rays.wavelength)
+        parts.append(outs[3:])
+    joined = []
+    for k in range(3):   # the sensor planes of the stretches, in slot order
+        have = [p[k] for p in parts if p[k].numel()]
+        joined.append(torch.cat(have, dim=0) if len(have) > 1 else have[0] if have else parts[0][k])
+    return (cur._pos, cur._dir, cur.intensity, *joined)
+
+
+def trace_sequential_with_grad(elements, rays, prog, group=None, whole=False):
     """Run the differentiable trace of `rays` (whose planes may carry a graph); returns the six outputs of
-    TraceSeqFn."""
+    TraceSeqFn.  A program longer than one sweep takes is differentiated in stretches (unless `whole`)."""
+    stretches = None if whole else _stretches(elements, prog)
+    if stretches is not None:
+        return _trace_stretches(stretches, rays, group)
     thetas = _cached_scalars(elements)
     table = tangent_table(elements, thetas)
     params, seen = [], set()

@@ -158,6 +158,26 @@ def _launch_prepared(handle, rec, dev, what, retry):
     return rec
 
 
+def _trace_pieces(rays, prog, out, n, dev, hit_p, w_p, mask_p):
+    """SequentialScene.simulate of a program longer than one launch takes: the pieces of `P.split_program` one after the
+    other, the first from `rays` into `out`, the others in place in `out`; every piece records into the planes of its
+    own sensor slots (hit_p, w_p, mask_p: addresses of the whole record's [K,3,N], [K,N], [K,N] planes, 0 = none)."""
+    lib = N.lib()
+    src = rays
+    for piece, _, slots in P.split_program(prog):
+        dp = N.DeviceProgram.upload(piece, dev)
+        has = P.n_sensor_slots(piece) > 0
+        code = _call_on(dev, lib.rtt_trace_seq_f32,
+                        src._pos.data_ptr(), src._dir.data_ptr(), src.intensity.data_ptr(), n,
+                        out._pos.data_ptr(), out._dir.data_ptr(), out.intensity.data_ptr(), n, n,
+                        dp.dev.data_ptr(), dp.host_ptr, dp.n,
+                        hit_p + 12 * slots * n if has else None, w_p + 4 * slots * n if has else None,
+                        mask_p + slots * n if has else None, n, N.stream_handle(dev))
+        if code:
+            N.check(code, "rtt_trace_seq_f32")
+        src = out
+
+
 def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
     """trace_sequential for the plain call (no moments): returns the launch's SensorRecord, or None for a program
     without sensor slots."""
@@ -172,6 +192,10 @@ def trace_sequential_record(rays: Rays, prog: np.ndarray, out: Rays = None):
             out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
         return SensorRecord(k, n, rays.device) if k else None
     dev = rays.device
+    if prog.shape[0] > P.MAX_SURFACES:   # a launch takes 64 surfaces: one launch per piece, each continuing in `out`
+        rec = SensorRecord(k, n, dev) if k else None
+        _trace_pieces(rays, prog, out, n, dev, *(rec.pointers() if k else (0, 0, 0)))
+        return rec
     handle = _prepared(prog, 0, rays, out, n, dev)
     if handle is not None:
         rec = SensorRecord(k, n, dev) if k else None
@@ -238,6 +262,11 @@ def trace_sequential(rays: Rays, prog: np.ndarray, out: Rays = None, moments=Non
             out._pos.copy_(rays._pos); out._dir.copy_(rays._dir); out.intensity.copy_(rays.intensity)
         if moments is not None:
             moments[1][:3] = 0.0
+        return sens_hit, sens_w, sens_mask
+    if prog.shape[0] > P.MAX_SURFACES:
+        if moments is not None:
+            raise ValueError("the trace that sums moments is one launch: at most %d surfaces" % P.MAX_SURFACES)
+        _trace_pieces(rays, prog, out, n, dev, N.ptr(sens_hit) or 0, N.ptr(sens_w) or 0, N.ptr(sens_mask) or 0)
         return sens_hit, sens_w, sens_mask
     dp = N.DeviceProgram.upload(prog, dev)
     if moments is not None:
@@ -315,15 +344,18 @@ def trace_sequential_history(rays: Rays, prog: np.ndarray):
     hist = torch.empty((s, 3, n), device=dev, dtype=torch.float32)
     hit_any = torch.zeros((s,), device=dev, dtype=torch.int32)
     if n and s:
-        dp = N.DeviceProgram.upload(prog, dev)
-        with torch.cuda.device(dev):
-            code = N.lib().rtt_trace_seq_history_f32(
-                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
-                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n,
-                N.ptr(dp.dev), dp.host_ptr, dp.n,
-                N.ptr(sens_hit), N.ptr(sens_w), N.ptr(sens_mask), n,
-                N.ptr(hist), N.ptr(hit_any), n, N.stream_handle(dev))
-        N.check(code, "rtt_trace_seq_history_f32")
+        for piece, first, slots in P.split_program(prog):   # (one piece unless the program is longer than a launch takes)
+            dp = N.DeviceProgram.upload(piece, dev)
+            has = P.n_sensor_slots(piece) > 0
+            with torch.cuda.device(dev):
+                code = N.lib().rtt_trace_seq_history_f32(
+                    N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n,
+                    N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(rays.intensity), n, n,
+                    N.ptr(dp.dev), dp.host_ptr, dp.n,
+                    N.ptr(sens_hit[slots:]) if has else None, N.ptr(sens_w[slots:]) if has else None,
+                    N.ptr(sens_mask[slots:]) if has else None, n,
+                    N.ptr(hist[first:]), N.ptr(hit_any[first:]), n, N.stream_handle(dev))
+            N.check(code, "rtt_trace_seq_history_f32")
     return sens_hit, sens_w, sens_mask, hist, hit_any
 
 
@@ -333,12 +365,13 @@ def intersect_test(rays: Rays, prog: np.ndarray) -> torch.Tensor:
     s = prog.shape[0]
     t = torch.empty((s, n), device=rays.device, dtype=torch.float32)
     if n and s:
-        dp = N.DeviceProgram.upload(prog, rays.device)
-        with torch.cuda.device(rays.device):
-            code = N.lib().rtt_intersect_test_f32(
-                N.ptr(rays._pos), N.ptr(rays._dir), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n,
-                N.ptr(t), n, N.stream_handle(rays.device))
-        N.check(code, "rtt_intersect_test_f32")
+        for piece, first, _ in P.split_program(prog):   # (one piece unless the program is longer than a launch takes)
+            dp = N.DeviceProgram.upload(piece, rays.device)
+            with torch.cuda.device(rays.device):
+                code = N.lib().rtt_intersect_test_f32(
+                    N.ptr(rays._pos), N.ptr(rays._dir), n, n, N.ptr(dp.dev), dp.host_ptr, dp.n,
+                    N.ptr(t[first:]), n, N.stream_handle(rays.device))
+            N.check(code, "rtt_intersect_test_f32")
     return t.t()
 
 
@@ -370,6 +403,8 @@ def ray_cast(rays: Rays, prog: np.ndarray):
     """winner [N] int32 (-1 = miss) and tmin [N]."""
     n = _check_rays(rays)
     dev = rays.device
+    if prog.shape[0] > P.MAX_SURFACES:
+        return _ray_cast_pieces(rays, prog, n, dev)
     winner = torch.full((n,), -1, device=dev, dtype=torch.int32)
     tmin = torch.full((n,), float("inf"), device=dev, dtype=torch.float32)
     if n and prog.shape[0]:
@@ -380,6 +415,49 @@ def ray_cast(rays: Rays, prog: np.ndarray):
                 N.ptr(winner), N.ptr(tmin), N.stream_handle(dev))
         N.check(code, "rtt_ray_cast_f32")
     return winner, tmin
+
+
+def _ray_cast_pieces(rays, prog, n, dev):
+    """Scene.ray_cast over more surfaces than one launch takes: a cast per piece of the program, then the row minimum
+    over the pieces by the rule of torch.min over the whole row (scene/base.py:165-170): the smaller distance wins, the
+    earlier surface on equal distances, and a NaN beats every number (the first one wins)."""
+    winner = torch.full((n,), -1, device=dev, dtype=torch.int32)
+    tmin = torch.full((n,), float("inf"), device=dev, dtype=torch.float32)
+    for piece, first, _ in P.split_program(prog):
+        w, t = ray_cast(rays, piece)
+        t_nan, m_nan = torch.isnan(t), torch.isnan(tmin)
+        take = (t_nan & ~m_nan) | (~t_nan & ~m_nan & (t < tmin))
+        tmin = torch.where(take, t, tmin)
+        winner = torch.where(take, w + first, winner)
+    return torch.where(tmin < float("inf"), winner, torch.full_like(winner, -1)), tmin
+
+
+def _step_pieces(rays, prog, out, n, dev, want_winner):
+    """Scene.step over more surfaces than one launch takes.  The cast over all pieces names every ray's surface; then one
+    bounce per piece on the rays whose surface lies in it (the others ride along with intensity 0, which a bounce leaves
+    alone), and the moved rays of all pieces are put together."""
+    winner, _ = _ray_cast_pieces(rays, prog, n, dev)
+    sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev, zero_mask=True)
+    new_pos, new_dir, new_int = rays._pos.clone(), rays._dir.clone(), rays.intensity.clone()
+    lib = N.lib()
+    for piece, first, slots in P.split_program(prog):
+        mine = (winner >= first) & (winner < first + piece.shape[0])
+        lit = torch.where(mine, rays.intensity, torch.zeros_like(rays.intensity))
+        pos_c, dir_c, int_c = torch.empty_like(rays._pos), torch.empty_like(rays._dir), torch.empty_like(lit)
+        dp = N.DeviceProgram.upload(piece, dev)
+        has = P.n_sensor_slots(piece) > 0
+        with torch.cuda.device(dev):
+            code = lib.rtt_step_nearest_f32(
+                N.ptr(rays._pos), N.ptr(rays._dir), N.ptr(lit), n, N.ptr(pos_c), N.ptr(dir_c), N.ptr(int_c), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n, None,
+                N.ptr(sens_hit[slots:]) if has else None, N.ptr(sens_w[slots:]) if has else None,
+                N.ptr(sens_mask[slots:]) if has else None, n, N.stream_handle(dev))
+        N.check(code, "rtt_step_nearest_f32")
+        new_pos = torch.where(mine[None, :], pos_c, new_pos)
+        new_dir = torch.where(mine[None, :], dir_c, new_dir)
+        new_int = torch.where(mine, int_c, new_int)
+    out._pos.copy_(new_pos); out._dir.copy_(new_dir); out.intensity.copy_(new_int)
+    return (winner if want_winner else None), sens_hit, sens_w, sens_mask
 
 
 def step_nearest_record(rays: Rays, prog: np.ndarray):
@@ -423,6 +501,8 @@ def step_nearest(rays: Rays, prog: np.ndarray, out: Rays = None, want_winner: bo
     elif _check_rays(out) != n:
         raise ValueError("`out` must hold the same number of rays")
     dev = rays.device
+    if n and prog.shape[0] > P.MAX_SURFACES:
+        return _step_pieces(rays, prog, out, n, dev, want_winner)
     launches = bool(n and prog.shape[0])
     sens_hit, sens_w, sens_mask = _sensor_buffers(prog, n, dev, zero_mask=not launches)   # the entry point clears the masks
     winner = torch.full((n,), -1, device=dev, dtype=torch.int32) if want_winner else None
@@ -688,7 +768,7 @@ def can_generate_in_trace(pend, prog) -> bool:
     """Whether rtt_sample_trace_seq_f32 takes this sample: a source of two uniforms per ray, an even global offset
     (a lane's pair of rays is one Philox block), and something to trace."""
     from .rays.ray import PendingSample
-    return (type(pend) is PendingSample and pend.n > 0 and prog.shape[0] > 0 and 0 <= pend.src.kind <= 6
+    return (type(pend) is PendingSample and pend.n > 0 and 0 < prog.shape[0] <= P.MAX_SURFACES and 0 <= pend.src.kind <= 6
             and pend.src.offset % 2 == 0)
 
 

@@ -133,8 +133,8 @@ class SpotSizeLoss(Goal):
         prog = scene._program()
         slots = [int(r["sensor_slot"]) for r in prog if int(r["sensor_slot"]) >= 0
                  and scene.elements[int(r["element_id"])] is self.sensor]
-        if len(slots) != 1 or P.n_sensor_slots(prog) != 1:
-            return None
+        if len(slots) != 1 or P.n_sensor_slots(prog) != 1 or not AG.one_sweep(prog, len(scene.elements)):
+            return None   # (a long program is differentiated in stretches, by the general path)
         from ..rays.ray import PendingTrace, SampledRays
         src = Rays.from_planes(rays._pos.detach(), rays._dir.detach(), rays.intensity.detach(), rays.id, rays.wavelength)
         k = slots[0]

@@ -169,11 +169,39 @@ def compile_elements(elements) -> np.ndarray:
                 rec["sensor_slot"] = n_sensor
                 n_sensor += 1
             recs.append(rec)
-    if len(recs) > MAX_SURFACES:
-        raise ValueError(f"scene has {len(recs)} surfaces; the kernels accept at most {MAX_SURFACES}")
     if not recs:
         return np.zeros((0,), dtype=SURFACE_DTYPE).view(Program)
     return np.stack(recs).view(Program)
+
+
+def split_program(prog, limit: int = MAX_SURFACES):
+    """A program of any length as pieces the kernels accept (at most `limit` records each, cut between elements: the
+    records of a polyhedron refer to their siblings): [(piece, index of its first record in `prog`, number of sensor
+    slots in front of it)].  The sensor slots of a piece are numbered from 0; a launch is given the planes of its first
+    slot.  The pieces of a `Program` are made once and kept with it."""
+    if prog.shape[0] <= limit:
+        return [(prog, 0, 0)]
+    facts = facts_of(prog)
+    key = ("pieces", limit)
+    if facts is not None and key in facts:
+        return facts[key]
+    plain = np.asarray(prog)
+    ids = plain["element_id"]
+    cuts = [0] + [int(i) for i in np.nonzero(ids[1:] != ids[:-1])[0] + 1] + [plain.shape[0]]   # first record of every element
+    pieces, start, slots = [], 0, 0
+    while start < plain.shape[0]:
+        end = max((c for c in cuts if start < c <= start + limit), default=None)
+        if end is None:
+            raise ValueError(f"an element of the scene has more than {limit} surfaces")
+        piece = plain[start:end].copy()
+        sensors = (piece["flags"] & F_SENSOR) != 0
+        piece["sensor_slot"][sensors] -= slots
+        pieces.append((piece.view(Program), start, slots))
+        slots += int(sensors.sum())
+        start = end
+    if facts is not None:
+        facts[key] = pieces
+    return pieces
 
 
 def n_sensor_slots(prog) -> int:

@@ -5,7 +5,6 @@ The reference materialises an [N, S] distance matrix, takes a row-min, then disp
 sub-batches from Python.  Here one kernel per bounce keeps the running (t_min, winner) in
 registers while it loops over the packed surface program, then applies the winner's interaction.
 """
-import operator
 
 import numpy as np
 import torch
@@ -206,7 +205,8 @@ class Scene(nn.Module):
         self._build_index_maps()
         if not hasattr(self.rays, "_snapshot") and len(self.elements) and self._needs_grad(self.rays):
             return self._bounce_with_grad(self.rays, self.Nbounces)
-        if hasattr(self.rays, "_snapshot") or len(self.elements) == 0 or self._has_fuzzy():
+        if (hasattr(self.rays, "_snapshot") or len(self.elements) == 0 or self._has_fuzzy()
+                or self.total_surfaces > P.MAX_SURFACES):   # (the fused bounce loop is one launch: at most 64 surfaces)
             # rays wrapped in Paths want a snapshot per bounce, and a Fuzzy filter changes intensities (which decide
             # whether a ray bounces on) between bounces: one launch per bounce, like the reference
             for _ in range(self.Nbounces):
@@ -246,6 +246,9 @@ class Scene(nn.Module):
             raise NotImplementedError("a Fuzzy filter in a differentiable trace: its function runs on the host and "
                                       "carries no gradient; trace under torch.no_grad()")
         prog = self._program()
+        if prog.shape[0] > P.MAX_SURFACES:
+            raise NotImplementedError(f"the differentiable nearest-hit bounce takes at most {P.MAX_SURFACES} surfaces "
+                                      f"(this scene has {prog.shape[0]}); a SequentialScene of any length is differentiable")
         pos, dir_, inten, hit, keys = AG.simulate_nearest_with_grad(self.elements, rays, prog, max_bounces,
                                                                     getattr(self, "_hit_capacity", None),
                                                                     group=getattr(self, "grad_group", None))
@@ -310,7 +313,7 @@ class Scene(nn.Module):
                 self.rays._snapshot()
             return
         prog = self._program()
-        if not recording and type(raw) is Rays:
+        if not recording and type(raw) is Rays and prog.shape[0] <= P.MAX_SURFACES:
             # the common call: plain rays in place, nobody asks for the winners
             rec = K.step_nearest_record(raw, prog)
             if rec is not None:

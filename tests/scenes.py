@@ -79,14 +79,29 @@ def system5(ns):
     ]
 
 
-def naive32(ns):
-    """C4: 6 singlets + 2 cylindrical singlets + mirror + sensor = 32 surfaces."""
+def naive32(ns, z0=0.0):
+    """C4: 6 singlets + 2 cylindrical singlets + mirror + sensor = 32 surfaces (`z0` moves the whole group along z)."""
     els = [ns.SingletLens(c1=0.03, c2=-0.02, d=12.0, t=2.0, ior_glass=1.5, inked=True,
-                          transform=T(ns, 8.0 * i)) for i in range(6)]
+                          transform=T(ns, z0 + 8.0 * i)) for i in range(6)]
     els += [ns.CylSingletLens(c1=0.02, c2=-0.02, height=14.0, width=14.0, t=2.0, ior_glass=1.5, inked=True,
-                              transform=T(ns, 50.0 + 8.0 * i)) for i in range(2)]
-    els.append(ns.SphericalMirror(c1=-0.01, d=0.0, diameter=30.0, transform=T(ns, 80.0)))
-    els.append(ns.Sensor(ns.Disk(20.0, transform=T(ns, 70.0))))
+                              transform=T(ns, z0 + 50.0 + 8.0 * i)) for i in range(2)]
+    els.append(ns.SphericalMirror(c1=-0.01, d=0.0, diameter=30.0, transform=T(ns, z0 + 80.0)))
+    els.append(ns.Sensor(ns.Disk(20.0, transform=T(ns, z0 + 70.0))))
+    return els
+
+
+def triplet_train(ns, count=10, grads=False, sensors=()):
+    """`count` weak triplets in a row, alternately converging and diverging so that a collimated beam stays inside
+    them (7 surfaces each: ten of them are more surfaces than one launch takes); a sensor behind every triplet whose
+    index is in `sensors`."""
+    els = []
+    for i in range(count):
+        sgn = 1.0 if i % 2 == 0 else -1.0
+        els.append(ns.TripletLens(c1=0.012 * sgn, c2=-0.006 * sgn, c3=0.004 * sgn, c4=-0.010 * sgn, d=12.0, t1=2.0, t2=1.0,
+                                  t3=2.5, ior_glass1=1.5, ior_glass2=1.65, ior_glass3=1.55, c1_grad=grads, c4_grad=grads,
+                                  ior_glass2_grad=grads, transform=T(ns, 9.0 * i, x=0.05 * (i % 3 - 1), rot=[0.002 * i, -0.001 * i, 0.0])))
+        if i in sensors:
+            els.append(ns.Sensor(ns.Disk(9.0, transform=T(ns, 9.0 * i + 4.5))))   # (a triplet is centred on its pose: +-2.75)
     return els
 
 

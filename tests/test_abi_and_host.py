@@ -282,9 +282,17 @@ def test_constructor_validation(ns):
     fres = ns.SingletLens(c1=0.05, c2=-0.05, d=10.0, t=3.0, ior_glass=1.5, fresnel=True)
     assert [type(f).__name__ for f in fres.surface_functions] == ["RefractFresnel"] * 3   # elements/lens.py:36-56
     assert int(fres._record(0)["phys_kind"]) == P.PHYS_FRESNEL
-    too_many = [scenes.singlet(ns) for _ in range(22)]
-    with pytest.raises(ValueError, match="at most"):
-        P.compile_elements(too_many)
+    # a program may be longer than a launch takes: the host cuts it between elements, sensor slots numbered per piece
+    many = [scenes.singlet(ns) for _ in range(21)] + [ns.Sensor(ns.Disk(5.0)), scenes.singlet(ns), ns.Sensor(ns.Disk(5.0))]
+    long = P.compile_elements(many)
+    assert long.shape[0] == 68 and P.n_sensor_slots(long) == 2
+    pieces = P.split_program(long)
+    assert [(p.shape[0], first, slots) for p, first, slots in pieces] == [(64, 0, 0), (4, 64, 1)]
+    assert P.split_program(long) is pieces                      # made once per program
+    assert [int(s) for s in pieces[0][0]["sensor_slot"][-1:]] == [0] and int(pieces[1][0]["sensor_slot"][-1]) == 0
+    assert len(P.split_program(long[:30])) == 1
+    with pytest.raises(ValueError, match="more than 2 surfaces"):
+        P.split_program(long, limit=2)
 
 
 def test_scene_bookkeeping(ns):

@@ -134,7 +134,8 @@ def _many_singlets(ns, count):
 @pytest.mark.parametrize("count,launches", [(6, "several"), (8, None)])
 def test_slot_budget_edges(ns, count, launches, monkeypatch):
     """19 surfaces leave room for 27 slot accumulators per launch, fewer than the wanted slots of six trainable
-    singlets, which therefore take several launches; 25 surfaces leave none and the forward-mode kernels take over."""
+    singlets, which therefore take several launches; 25 surfaces leave none for one sweep, and the program is swept in
+    stretches of whole elements (a single element that long is left to the forward-mode kernels)."""
     def build():
         return _many_singlets(ns, count), scenes.disk_bundle(ns, radius=3.0, z=-10.0).sample(3001).to(DEV)
     n_surf = 3 * count + 1
@@ -143,9 +144,9 @@ def test_slot_budget_edges(ns, count, launches, monkeypatch):
     calls = []
     obj_a, ga = _grads(ns, build, _projection(ns, 1), "adjoint", monkeypatch, calls)
     obj_t, gt = _grads(ns, build, _projection(ns, 1), "tangent", monkeypatch)
-    assert obj_a == obj_t
+    assert abs(obj_a - obj_t) <= 1e-6 * abs(obj_t)
     if launches is None:
-        assert budget == 0 and not calls
+        assert budget == 0 and len(calls) >= 2
     else:
         assert len(calls) >= 2, (len(calls), budget)
     _compare(ga, gt)
