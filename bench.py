@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--tune-cull", type=int, default=-1, help="0: nearest-hit kernels test every surface (experiment)")
     ap.add_argument("--tune-adjoint-lane", type=int, default=0, help="rays per lane of the reverse-mode backward: 1, 2, 0 = automatic")
     ap.add_argument("--tune-adjoint-rounds", type=int, default=0, help="rounds of resident blocks in the grid of the reverse-mode backward (experiment)")
+    ap.add_argument("--tune-late-records", type=int, default=-1, help="0: every stage of the staged bounce loop writes the output planes itself (experiment)")
     ap.add_argument("--tune-adjoint-state", type=int, default=-1, help="1: the reverse-mode backward keeps its states in LDS also for short programs")
     return ap.parse_args()
 
@@ -285,6 +286,7 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
     rays = mk(pos, d)
     kernel = "k_trace_seq"
     pre = None   # untimed preparation of a step, where the step consumes its input
+    extra_bytes = None   # algorithmic bytes of a step beyond bytes_per_ray * n, known once a step has run
     if a.workload == "system5":
         elements = scenes.system5(ns)
         scene = ns.SequentialScene(elements)
@@ -332,6 +334,9 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
             else:
                 scene.simulate()
         bytes_per_ray = 56
+
+        def extra_bytes():   # every crossing of the sensor is appended to its hit list: 16 B of hit + 8 B of key
+            return 24 * sum(int(x.shape[0]) for x in scene.elements[-1].hitLocs)
     elif a.workload == "naive32":
         scene = ns.Scene()
         for el in scenes.naive32(ns):
@@ -382,6 +387,8 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
             prepare()
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    import raytracetorch_amd.sharding as sharding
+    collectives = sharding.collective_times = [] if (a.workload == "spot" and dist is not None) else None
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     idle = 0.0
@@ -394,10 +401,12 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0 - idle
     elapsed = max_over_ranks(elapsed, dist, dev)
+    sharding.collective_times = None
     stats = timing_stats([s.elapsed_time(e) for s, e in ev])
     gpu_ms = stats["kernel_ms"]
     if rank == 0:
-        achieved = bytes_per_ray * n / (gpu_ms * 1e-3) / 1e9
+        algorithmic = bytes_per_ray * n + (extra_bytes() if extra_bytes else 0)
+        achieved = algorithmic / (gpu_ms * 1e-3) / 1e9
         traffic, traffic_note = measured_traffic(a.workload, n)
         line = {
             "metric": "ray-surface intersections/sec", "value": world * n * surfaces / (elapsed / a.steps),
@@ -408,12 +417,15 @@ def other_workload(a, ns, scenes, dev, rank, world, dist):
                        "ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                        "parallelism": (f"rays sharded over {world} GPU(s); "
                                        + ("sums of a few float64 (spot moments, loss, parameter gradients) all-reduced"
-                                          if a.workload == "spot" else "no data-path collective"))},
+                                          if a.workload == "spot" else "no data-path collective")),
+                       # rank 0's event time inside the all-reduces of one step (it includes waiting for the slowest rank)
+                       **({"collective_ms": sharding.collective_ms(collectives) / a.steps,
+                           "collectives_per_step": len(collectives) / a.steps} if collectives is not None else {})},
             "rays_per_s": world * n / (elapsed / a.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": kernel, **stats,
-                         "algorithmic_bytes_per_launch": bytes_per_ray * n,
+                         "algorithmic_bytes_per_launch": algorithmic,
                          "issue": measured_issue(a.workload, n),
                          "note": "event time spans every kernel of the step, including torch glue"}}
         base = None if (world > 1 or a.no_cpu_baseline) else cpu_baseline_other(a.workload, scenes, ns)
@@ -472,6 +484,8 @@ def main():
         _native.check(_native.lib().rtt_tune(3, a.tune_cull), "rtt_tune")
     if a.tune_adjoint_lane:
         _native.check(_native.lib().rtt_tune(6, a.tune_adjoint_lane), "rtt_tune")
+    if a.tune_late_records >= 0:
+        _native.check(_native.lib().rtt_tune(10, a.tune_late_records), "rtt_tune")
     if a.tune_adjoint_rounds:
         _native.check(_native.lib().rtt_tune(9, a.tune_adjoint_rounds), "rtt_tune")
     if a.tune_adjoint_state >= 0:

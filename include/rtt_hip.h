@@ -476,7 +476,10 @@ int64_t rtt_sensor_record_bytes(int n_slots, int64_t sens_ld);
  * positions walked again) for programs of at most 6 surfaces where that lets a third wavefront per SIMD in, 1 always
  * the full states;
  * key 8: threads per block of rtt_spot_moments_f32 on 16-byte aligned records, 1024 (default) or 256;
- * key 9: size of the grid of the reverse sweeps in rounds of resident blocks, 1 .. 8 (default 3, at most 2048 blocks).
+ * key 9: size of the grid of the reverse sweeps in rounds of resident blocks, 1 .. 8 (default 3, at most 2048 blocks);
+ * key 10: rtt_simulate_nearest_staged_f32: 1 (default) rays that come to rest after the first stage leave one 32-byte
+ * record each and a last pass writes them to the output planes in index order, 0 every stage writes the planes itself
+ * (seven scattered 4-byte stores per such ray).  Same results.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

@@ -19,7 +19,7 @@ if len(sys.argv) < 6 and not os.environ.get("RTT_PROFILE_STEPS"):
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else int(os.environ["RTT_PROFILE_STEPS"])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.environ.get("RTT_HIP_LIB") or os.path.join(ROOT, "raytracetorch_amd", "csrc", "librtt_hip.so")
-OWN = ("k_trace_seq", "k_simulate_nearest", "k_ray_cast", "k_spot_moments", "k_sum_partials", "k_sample_bundle")
+OWN = ("k_trace_seq", "k_simulate_nearest", "k_place_late", "k_ray_cast", "k_spot_moments", "k_sum_partials", "k_sample_bundle")
 
 
 def short(name):

@@ -1127,7 +1127,8 @@ struct SensorIO {
   float* lane_mom;
   int32_t mom_slot;
   // append mode when the launch holds a compacted subset of the call's rays: the keys of the lane's rays
-  int32_t use_lane_key, lane_key[2];
+  // (the keys live in the lane's column of the block's LDS, kBlock entries apart: they are read at a sensor only)
+  const int32_t* lane_key;
   // one bounce with dense slots: a ray writes its mask entry only on the sensor it goes to, so every lane first clears
   // the entries of its rays on the first zero_slots slots (0: the caller cleared the planes)
   int32_t zero_slots;
@@ -1217,7 +1218,7 @@ DI void record_sensor(const SensorIO& se, int slot, IX i, M hit, V3<T> hl, T I, 
         h[2] = comp(hl.z, k);
         h[3] = comp(I, k);
         se.app_key[2 * (int64_t)at] = se.bounce * RTT_MAX_SURFACES + slot;
-        se.app_key[2 * (int64_t)at + 1] = se.use_lane_key ? se.lane_key[k] : (int32_t)(se.index0 + (int64_t)i + k);
+        se.app_key[2 * (int64_t)at + 1] = se.lane_key ? se.lane_key[k * kBlock] : (int32_t)(se.index0 + (int64_t)i + k);
       }
     }
     return;
@@ -1926,10 +1927,19 @@ struct StageIO {
   int32_t* next_count;      // device counter of the next stage, zero at launch
   int64_t next_ld;
   int32_t bounce0;          // bounces of the loop that lie before this stage
+  // A ray that comes to rest in a later stage sits anywhere in the call: seven 4-byte stores to its places in the
+  // caller's planes would each dirty a 32-byte sector of its own.  Such a ray leaves one 32-byte record (position,
+  // direction, intensity, bounce count) at its index in `rec` instead, the first stage marks in `late` who moved on,
+  // and k_place_late writes the records to the planes in index order once the last stage is through.
+  float* rec;               // [n][8]; null = every stage writes the planes itself
+  uint8_t* late;            // [n]
 };
 
+#ifndef RTT_STAGE_WAVES
+#define RTT_STAGE_WAVES 4
+#endif
 template <class T, bool SINGLE, bool STAGE = false>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STAGE ? RTT_STAGE_WAVES : 4, 4))) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                              Ops ops, Cull cull, int max_bounces_,
                                                              int32_t* __restrict__ winner,
                                                              int32_t* __restrict__ bounces_out, SensorIO se, int vec,
@@ -1956,27 +1966,29 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     const int nv = (n_in - i) >= N ? N : 1;
     Ray<T> r = load_ray<T>(io, i, vec != 0, nv);
     bool open[N];   // the ray may still move: it has not missed yet
-    int taken[N];
-    int orig[N];    // STAGE: index of the ray in the call
-    int last[N];    // STAGE: the surface the ray met last
+    int taken[N];   // bounces taken (STAGE: kept in LDS, see below)
+    // STAGE: what a ray carries through the stages besides its state -- its index in the call, its bounce count, the
+    // surface it met last -- is needed at a sensor and at the hand-over only.  It lives in the lane's column of the
+    // block's LDS: in registers it pushes the bounce loop over what four wavefronts per SIMD may hold, and what the
+    // compiler then spills travels to HBM and back.
+    __shared__ int32_t s_carried[STAGE ? 3 * N * kBlock : 1];
+    int32_t* const carried = s_carried + (STAGE ? threadIdx.x : 0);
+#define RTT_ORIG(k) carried[(k) * kBlock]
+#define RTT_TAKEN(k) carried[(N + (k)) * kBlock]
+#define RTT_LAST(k) carried[(2 * N + (k)) * kBlock]
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       open[k] = live && k < nv;
       taken[k] = 0;
-      last[k] = 0;
-      orig[k] = (int)(i + k);
       if (STAGE) {
         const int64_t at = i + (k < nv ? k : 0);
-        if (st.orig_in) orig[k] = st.orig_in[at];
-        if (st.taken_in) taken[k] = st.taken_in[at];
+        RTT_ORIG(k) = st.orig_in ? st.orig_in[at] : (int)(i + k);
+        RTT_TAKEN(k) = st.taken_in ? st.taken_in[at] : 0;
+        RTT_LAST(k) = 0;
       }
     }
     SensorIO seb = se;
-    if (STAGE) {
-      seb.use_lane_key = 1;
-#pragma unroll
-      for (int k = 0; k < N; ++k) seb.lane_key[k] = orig[k];
-    }
+    if (STAGE) seb.lane_key = carried;
     if (SINGLE && live) {
       for (int slot = 0; slot < se.zero_slots; ++slot) {
         uint8_t* m = se.mask + (int64_t)slot * se.ld + i;
@@ -2018,8 +2030,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         const bool won = icomp(win, k) >= 0;
         if (a && !won) open[k] = false;
         pend = set_mask(pend, k, a && won);
-        taken[k] += (a && won) ? 1 : 0;
-        if (STAGE) last[k] = (a && won) ? icomp(win, k) : last[k];
+        if (STAGE) {
+          if (a && won) {
+            RTT_TAKEN(k) += 1;
+            RTT_LAST(k) = icomp(win, k);
+          }
+        } else {
+          taken[k] += (a && won) ? 1 : 0;
+        }
       }
       serve_winners<T>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
     }
@@ -2036,9 +2054,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
       if (threadIdx.x < RTT_MAX_SURFACES) s_hist[threadIdx.x] = 0;
       __syncthreads();
       bool go_on[N];
-      int rank[N];
+      int rank[N], orig[N], last[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
+        orig[k] = RTT_ORIG(k);
+        taken[k] = RTT_TAKEN(k);
+        last[k] = RTT_LAST(k);
         go_on[k] = live && k < nv && st.next_pos != nullptr && open[k] && comp(r.I, k) > 0.0f;
         rank[k] = go_on[k] ? atomicAdd(&s_hist[last[k] & (RTT_MAX_SURFACES - 1)], 1) : 0;
       }
@@ -2069,6 +2090,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
           st.next_inten[at] = comp(r.I, k);
           st.next_orig[at] = orig[k];
           st.next_taken[at] = taken[k];
+        } else if (mine && st.rec && st.orig_in) {
+          float4* q = reinterpret_cast<float4*>(st.rec + 8 * (int64_t)orig[k]);
+          q[0] = make_float4(comp(r.p.x, k), comp(r.p.y, k), comp(r.p.z, k), comp(r.d.x, k));
+          q[1] = make_float4(comp(r.d.y, k), comp(r.d.z, k), comp(r.I, k), __int_as_float(taken[k]));
         } else if (mine) {
           const int64_t o = orig[k];
           io.pos_out[o] = comp(r.p.x, k);
@@ -2080,10 +2105,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
           io.inten_out[o] = comp(r.I, k);
           if (bounces_out) bounces_out[o] = taken[k];
         }
+        if (mine && st.late && !st.orig_in) st.late[orig[k]] = go_on[k] ? 1 : 0;   // (first stage: rays in order)
       }
       __syncthreads();  // the counts are reused by the block's next round
       continue;
     }
+#undef RTT_ORIG
+#undef RTT_TAKEN
+#undef RTT_LAST
     if (!live) continue;
     store_ray<T>(io, i, r, vec != 0, nv);
     if (bounces_out) {
@@ -2091,6 +2120,26 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
       for (int k = 0; k < N; ++k)
         if (k < nv) bounces_out[i + k] = taken[k];
     }
+  }
+}
+
+// Last pass of the staged bounce loop: the rays that came to rest after the first stage, from their records to their
+// places in the caller's planes.  In index order, so that what a wavefront writes to a plane lies in one stretch.
+__global__ void __launch_bounds__(kBlock) k_place_late(const uint8_t* __restrict__ late, const float* __restrict__ rec,
+                                                       RayIO io, int32_t* __restrict__ bounces_out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < io.n; o += stride) {
+    if (!late[o]) continue;
+    const float4* q = reinterpret_cast<const float4*>(rec + 8 * o);
+    const float4 a = q[0], b = q[1];
+    io.pos_out[o] = a.x;
+    io.pos_out[io.ld_out + o] = a.y;
+    io.pos_out[2 * io.ld_out + o] = a.z;
+    io.dir_out[o] = a.w;
+    io.dir_out[io.ld_out + o] = b.x;
+    io.dir_out[2 * io.ld_out + o] = b.y;
+    io.inten_out[o] = b.z;
+    if (bounces_out) bounces_out[o] = __float_as_int(b.w);
   }
 }
 
@@ -3093,6 +3142,7 @@ int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, bool compact
 constexpr int kMaxDevices = 64;
 int g_adjoint_state = 0;                     // 0: compact states where they buy a third wavefront per SIMD, 1: full states always
 
+int g_late_records = 1;                      // staged bounce loop: rays that rest after the first stage leave records (1) or write the planes themselves (0)
 int g_adjoint_rounds = 3;                    // rounds of resident blocks in the grid of the reverse sweep (capped at 2048 blocks)
 
 // Compute units of the current device (256 on an MI355X), asked once per device.
@@ -3555,11 +3605,12 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
 }
 
 // workspace of the staged loop: kStageCounters int32 counters, then two sets of compact planes (pos 3, dir 3, intensity,
-// index, bounce count: 9 words per ray) of `cap` rays each, cap = n rounded up to an even number
+// index, bounce count: 9 words per ray) of `cap` rays each, cap = n rounded up to an even number, then the records of
+// the rays that come to rest late (8 words per ray) and their marks (a byte per ray)
 int64_t rtt_simulate_nearest_staged_workspace_bytes(int64_t n) {
   if (n < 0) return 0;
   const int64_t cap = (n + 1) & ~(int64_t)1;
-  return 256 + 2 * 9 * 4 * cap;
+  return 256 + ((2 * 9 * 4 * cap + 255) & ~(int64_t)255) + 8 * 4 * cap + cap;   // (a record fills one 32-byte sector)
 }
 
 int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,
@@ -3599,6 +3650,8 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
   int32_t* counters = (int32_t*)workspace;
   const int64_t cap = (n + 1) & ~(int64_t)1;
   float* sets[2] = {(float*)((char*)workspace + 256), (float*)((char*)workspace + 256) + 9 * cap};
+  float* rec = (float*)((char*)workspace + 256 + ((2 * 9 * 4 * cap + 255) & ~(int64_t)255));
+  uint8_t* late = (uint8_t*)(rec + 8 * cap);
   SensorIO se = {};
   se.app_hit = hit_list;
   se.app_key = hit_keys;
@@ -3627,6 +3680,9 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
       st.orig_in = (const int32_t*)(in + 7 * cap);
       st.taken_in = (const int32_t*)(in + 8 * cap);
     }
+    const bool records = g_late_records != 0;
+    st.rec = records ? rec : nullptr;
+    st.late = (records && s == 0 && !last) ? late : nullptr;
     if (!last) {
       float* out = sets[s & 1];
       st.next_pos = out;
@@ -3644,6 +3700,11 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
                        (int32_t*)nullptr, bounces, se, vec, st);
     if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
     done += todo;
+    if (last && s > 0 && g_late_records) {
+      RayIO place = {nullptr, nullptr, nullptr, 0, pos_out, dir_out, inten_out, ld_out, n};
+      hipLaunchKernelGGL(k_place_late, dim3(grid_for(n)), dim3(kBlock), 0, sm, (const uint8_t*)late, (const float*)rec, place, bounces);
+      if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
+    }
   }
   return RTT_OK;
 }
@@ -3907,6 +3968,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 7 && (value == 0 || value == 1)) {
     g_adjoint_state = value;
+    return RTT_OK;
+  }
+  if (key == 10 && (value == 0 || value == 1)) {
+    g_late_records = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;

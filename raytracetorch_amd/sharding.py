@@ -17,20 +17,42 @@ def shard_bounds(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+# While somebody measures (the benchmark), a list that receives one entry per all-reduce: a pair of CUDA events around
+# a collective on device tensors over RCCL, or the host seconds of one that went through the host.
+collective_times = None
+
+
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over the ranks of `group`; identity when `group` is None."""
     if group is None:
         return t
     import torch.distributed as dist
+    log = collective_times
     if t.is_cuda and dist.get_backend(group) == "gloo":
         # gloo is the rehearsal backend (two ranks on one GPU, CPU tests); its own staging of device tensors has
         # been seen to hang when two processes share a GPU, and these sums are a few doubles: reduce them on the host
+        import time
+        t0 = time.perf_counter()
         host = t.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         t.copy_(host)
+        if log is not None:
+            log.append(time.perf_counter() - t0)
+        return t
+    if log is not None and t.is_cuda:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        end.record()
+        log.append((start, end))
         return t
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def collective_ms(log) -> float:
+    """Sum of the entries `allreduce_sum_` left in `log`, in milliseconds (the device must have finished them)."""
+    return sum(e[0].elapsed_time(e[1]) if isinstance(e, tuple) else e * 1e3 for e in log)
 
 
 def gather_sensor_hits(sensor, group=None, ray_id=None):

@@ -114,7 +114,7 @@ def test_entry_points_validate_before_touching_the_gpu():
     src.area_kind, src.emit_kind = 1, 1
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 0, 0) == 0
     # the staged bounce loop: distinct output planes, an aligned workspace of the stated size, no Fresnel surface
-    assert lib.rtt_simulate_nearest_staged_workspace_bytes(7) == 256 + 2 * 9 * 4 * 8
+    assert lib.rtt_simulate_nearest_staged_workspace_bytes(7) == 256 + 768 + (8 * 4 + 1) * 8   # counters, two sets of compact planes (to 256 B), records and marks of 8 rays
     big = (ctypes.c_float * 1024)()
     ws = (ctypes.addressof(big) + 255) & ~255
     q = p + 128

@@ -12,9 +12,22 @@ dev = torch.device("cuda", 0)
 n = 16 * 2 ** 20
 b = ns.CollimatedDisk(radius=4.0, ray_id=0, device=dev, transform=ns.RayTransformBundle(translation=[0.0, 0.0, -30.0]).to(dev))
 r = b.sample(n, seed=1000)
-order = torch.argsort(r._pos[0] ** 2 + r._pos[1] ** 2)
+rad2 = r._pos[0] ** 2 + r._pos[1] ** 2
+order = torch.argsort(rad2)
+# what a regrouping inside the kernel could reach at best: the rays of every tile of `tile` consecutive rays (512 = one
+# block, 128 = one wavefront of two rays per lane) ordered by radius, i.e. live rays first within the tile, at no cost
+def within_tiles(tile):
+    key = torch.arange(n, device=dev) // tile * 1024.0 + rad2.double()      # (radius^2 <= 16)
+    return torch.argsort(key)
 mk = lambda p, q: ns.Rays.from_planes(p, q, torch.ones(n, device=dev), torch.zeros(n, device=dev, dtype=torch.int8), torch.zeros(n, device=dev))
-for label, rays in (("random order", mk(r._pos, r._dir)), ("sorted by radius", mk(r._pos[:, order].contiguous(), r._dir[:, order].contiguous()))):
+pick = lambda o: mk(r._pos[:, o].contiguous(), r._dir[:, o].contiguous())
+dead = rad2 > 3.5 ** 2                                                      # (what the inverted stop of radius 3.5 kills, about)
+for tile in (128, 512):
+    d = dead[within_tiles(tile)].view(-1, 128).float().mean(dim=1)
+    print(f"tiles of {tile}: wavefronts all live {float((d == 0).float().mean()):.3f}, all dead {float((d == 1).float().mean()):.3f}, "
+          f"mixed {float(((d > 0) & (d < 1)).float().mean()):.3f}", flush=True)
+for label, rays in (("random order", mk(r._pos, r._dir)), ("sorted in tiles of 512", pick(within_tiles(512))),
+                    ("sorted in tiles of 4096", pick(within_tiles(4096))), ("sorted by radius", pick(order))):
     out = mk(torch.empty_like(r._pos), torch.empty_like(r._dir))
     els = scenes.system5(ns)
     scene = ns.SequentialScene(els)
