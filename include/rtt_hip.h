@@ -477,9 +477,10 @@ int64_t rtt_sensor_record_bytes(int n_slots, int64_t sens_ld);
  * the full states;
  * key 8: threads per block of rtt_spot_moments_f32 on 16-byte aligned records, 1024 (default) or 256;
  * key 9: size of the grid of the reverse sweeps in rounds of resident blocks, 1 .. 8 (default 3, at most 2048 blocks);
- * key 10: rtt_simulate_nearest_staged_f32: 1 (default) rays that come to rest after the first stage leave one 32-byte
- * record each and a last pass writes them to the output planes in index order, 0 every stage writes the planes itself
- * (seven scattered 4-byte stores per such ray).  Same results.
+ * key 10: rtt_simulate_nearest_staged_f32: 0 (default) every stage writes the rays that come to rest to the output
+ * planes itself (seven scattered 4-byte stores for a ray that rests after the first stage), 1 such rays leave one
+ * 32-byte record each and a last pass writes them to the planes in index order (measured on the 32-surface scene,
+ * 4 Mi rays x 100 bounces: 8 % fewer HBM bytes, 1.5 % more time: the last pass).  Same results.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

@@ -1959,6 +1959,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STA
   const int64_t rounds = (((n_in + N - 1) / N << shift) * N + stride - 1) / stride;
   const CullLanes cl = cull_lanes(cull, ops);
   for (int64_t rnd = 0; rnd < rounds; ++rnd) {
+    // a block whose first lane lies beyond the rays has nothing to do in this round or any later one (a late stage
+    // fills a fraction of its grid: the others leave before they touch registers that spill)
+    if ((((rnd * (stride / N) + (int64_t)blockIdx.x * kBlock) >> shift) * N) >= n_in) break;
     const int64_t slot = rnd * (stride / N) + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // lane of the grid, all rounds
     const int64_t want = (slot >> shift) * N;
     const bool live = want < n_in && (slot & ((1 << shift) - 1)) == 0;
@@ -3142,7 +3145,7 @@ int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, bool compact
 constexpr int kMaxDevices = 64;
 int g_adjoint_state = 0;                     // 0: compact states where they buy a third wavefront per SIMD, 1: full states always
 
-int g_late_records = 1;                      // staged bounce loop: rays that rest after the first stage leave records (1) or write the planes themselves (0)
+int g_late_records = 0;                      // staged bounce loop: rays that rest after the first stage write the planes themselves (0) or leave records (1)
 int g_adjoint_rounds = 3;                    // rounds of resident blocks in the grid of the reverse sweep (capped at 2048 blocks)
 
 // Compute units of the current device (256 on an MI355X), asked once per device.

@@ -485,19 +485,26 @@ def test_staged_bounce_loop_equals_the_single_launch(ns, case, n, monkeypatch):
     prog = scene._program()
     src = b.sample(n, seed=31, offset=0)
     src._pos
+    from raytracetorch_amd import _native as N
     results = []
-    for min_rays in (1 << 40, 1):
+    # (single launch; stages that write the output planes themselves; stages whose late rays leave records for a last pass)
+    for min_rays, late_records in ((1 << 40, 0), (1, 0), (1, 1)):
         monkeypatch.setattr(K, "STAGED_MIN_RAYS", min_rays)
         assert K.staged_bounce_loop(n, bounces, prog) == (min_rays == 1)
         rays = src.clone()
-        taken, (hit, keys) = K.simulate_nearest(rays, prog, bounces, want_bounces=True, first_capacity=1000 if case == "cavity" else None)
+        assert N.lib().rtt_tune(10, late_records) == 0
+        try:
+            taken, (hit, keys) = K.simulate_nearest(rays, prog, bounces, want_bounces=True, first_capacity=1000 if case == "cavity" else None)
+        finally:
+            N.lib().rtt_tune(10, 0)
         order = torch.argsort(keys[:, 0].to(torch.int64) * (n + 1) + keys[:, 1].to(torch.int64))
         results.append((rays, taken, hit[order], keys[order]))
-    (ra, ta, ha, ka), (rb, tb, hb, kb) = results
-    for x, y in ((ra._pos, rb._pos), (ra._dir, rb._dir), (ra.intensity, rb.intensity)):
-        assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
-    assert torch.equal(ta, tb) and int(ta.max()) > 5
-    assert ka.shape[0] > 0 and torch.equal(ka, kb) and torch.equal(ha, hb)
+    ra, ta, ha, ka = results[0]
+    for rb, tb, hb, kb in results[1:]:
+        for x, y in ((ra._pos, rb._pos), (ra._dir, rb._dir), (ra.intensity, rb.intensity)):
+            assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0))
+        assert torch.equal(ta, tb) and int(ta.max()) > 5
+        assert ka.shape[0] > 0 and torch.equal(ka, kb) and torch.equal(ha, hb)
 
 
 def test_staged_entry_point_without_bounces_copies_the_rays_through(ns):

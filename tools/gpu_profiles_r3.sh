@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round-3 profiles: kernel stats + counters of every workload with the current library, traffic files with its hash.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for spec in "singlet 67108864" "system5 16777216" "naive32 4194304" "spot 33554432" "naive_sim 4194304" "sample_trace 67108864"; do
+  set -- $spec
+  rm -rf gpurun_out/prof_$1
+  bash profiles/run_pmc.sh $1 --workload $1 > gpurun_out/pmc_$1.txt 2>&1 || { echo "pmc $1 failed"; tail -5 gpurun_out/pmc_$1.txt; exit 1; }
+  python3 profiles/make_traffic.py gpurun_out/prof_$1 $1 $2 gpurun_out/traffic_$1.json 7 > /dev/null || exit 1   # run_pmc.sh: 5 steps + 2 warm-up
+  grep -v "at::native\|rocclr\|Cijk" gpurun_out/prof_$1/summary.txt > gpurun_out/$1_rocprofv3_summary.txt
+  python3 -c "import json; d=json.load(open('gpurun_out/traffic_$1.json')); print('$1', d['lib_sha16'], 'HBM MB per step %.1f' % (d['traffic_bytes_per_launch']/1e6))"
+done
