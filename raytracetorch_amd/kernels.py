@@ -136,16 +136,21 @@ def _prepared(prog, kind, src, dst, n, dev):
     for entry in kept:
         r = entry[0]
         if r[0]() is a and r[1]() is b and r[2]() is c and r[3]() is d and r[4]() is e and r[5]() is f and entry[1] == n:
-            return entry[2]
+            # the handle holds addresses: a tensor object whose storage was exchanged (`t.data = ...`, `set_`) is another launch
+            if entry[4] == (a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), e.data_ptr(), f.data_ptr()):
+                return entry[2]
+            kept.remove(entry)
+            break
     dp = N.DeviceProgram.upload(prog, dev)
     lib = N.lib()
+    where = (a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), e.data_ptr(), f.data_ptr())
     with torch.cuda.device(dev):
         handle = N.PreparedLaunch(lib.rtt_prepare_step_nearest_f32 if kind else lib.rtt_prepare_trace_seq_f32,
-                                  a.data_ptr(), b.data_ptr(), c.data_ptr(), n, d.data_ptr(), e.data_ptr(), f.data_ptr(), n, n,
+                                  where[0], where[1], where[2], n, where[3], where[4], where[5], n, n,
                                   dp.dev.data_ptr(), dp.host_ptr, dp.n, n)
     if len(kept) >= 4:
         del kept[0]
-    kept.append((tuple(weakref.ref(t) for t in (a, b, c, d, e, f)), n, handle, dp))   # (dp: the device copy the handle reads)
+    kept.append((tuple(weakref.ref(t) for t in (a, b, c, d, e, f)), n, handle, dp, where))   # (dp: the device copy the handle reads)
     return handle
 
 

@@ -113,6 +113,26 @@ def test_entry_points_validate_before_touching_the_gpu():
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 8, 0) == E_KIND
     src.area_kind, src.emit_kind = 1, 1
     assert lib.rtt_sample_bundle_f32(sp, p, p, 8, 0, 0, 0, 0, 0) == 0
+    # prepared launches: the arguments are checked when the handle is made; a handle made before an rtt_tune call is stale
+    h = ctypes.c_void_p()
+    prep = lambda *a: lib.rtt_prepare_trace_seq_f32(*a, ctypes.byref(h))
+    assert lib.rtt_prepare_trace_seq_f32(p, p, p, 8, p, p, p, 8, 8, p, hp, 1, 8, None) == E_NULL    # nowhere to put the handle
+    assert prep(0, p, p, 8, p, p, p, 8, 8, p, hp, 1, 8) == E_NULL and not h.value
+    assert prep(p, p, p, 8, p, p, p, 8, 8, p, 0, 1, 8) == E_NULL                                     # needs the host copy
+    assert prep(p, p, p, 8, p, p, p, 8, 0, p, hp, 1, 8) == E_SIZE                                    # nothing to launch
+    assert prep(p, p, p, 4, p, p, p, 8, 8, p, hp, 1, 8) == E_SIZE
+    assert prep(p + 2, p, p, 8, p, p, p, 8, 8, p, hp, 1, 8) == E_ALIGN
+    assert prep(p, p, p, 8, p, p, p, 8, 8, p, bad.ctypes.data, 1, 8) == E_KIND
+    assert prep(p, p, p, 8, p, p, p, 8, 8, p, sens.ctypes.data, 1, 4) == E_SIZE                      # sensor planes shorter than the bundle
+    assert lib.rtt_prepare_step_nearest_f32(p, p, p, 8, p, p, p, 8, 8, p, sens.ctypes.data, 1, 8, ctypes.byref(h)) == 0 and h.value
+    assert lib.rtt_launch_prepared(None, p, 0) == E_NULL
+    assert lib.rtt_launch_prepared(h, None, 0) == E_NULL                                             # a sensor surface, no record
+    assert lib.rtt_tune(3, 1) == 0                                                                   # (the default value: only the epoch moves)
+    assert lib.rtt_launch_prepared(h, p, 0) == E_KIND                                                # stale: prepare again
+    lib.rtt_release_prepared(h)
+    lib.rtt_release_prepared(None)
+    assert lib.rtt_sensor_record_bytes(2, 10) == 340 and lib.rtt_sensor_record_bytes(1, 3) == 52 and lib.rtt_sensor_record_bytes(0, 8) == 0
+    assert lib.rtt_tune(10, 2) == E_SIZE and lib.rtt_tune(10, 0) == 0 and lib.rtt_tune(11, 0) == E_SIZE
     # the staged bounce loop: distinct output planes, an aligned workspace of the stated size, no Fresnel surface
     assert lib.rtt_simulate_nearest_staged_workspace_bytes(7) == 256 + 768 + (8 * 4 + 1) * 8   # counters, two sets of compact planes (to 256 B), records and marks of 8 rays
     big = (ctypes.c_float * 1024)()

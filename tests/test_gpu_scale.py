@@ -685,3 +685,47 @@ def test_spot_loss_at_the_size_one_gpu_holds_in_configuration_5(ns):
         scene.grad_group = None
         if made:
             dist.destroy_process_group()
+
+
+def test_prepared_launches_equal_the_plain_entry_points(ns):
+    """rtt_prepare_* + rtt_launch_prepared against rtt_trace_seq_f32 / rtt_step_nearest_f32 called directly: rays and
+    sensor records bit for bit; the host side finds a handle again by its planes, makes a new one when a plane tensor
+    got other storage, and prepares again after an rtt_tune call."""
+    from raytracetorch_amd import kernels as K, _native as N
+    n = 20001
+    for kind, els in ((0, scenes.system5(ns)), (1, scenes.naive32(ns))):
+        prog = P.compile_elements(els)
+        k = P.n_sensor_slots(prog)
+        src = device_disk_rays(ns, n, seed=5, radius=5.0, z=-10.0, tilt=0.02)
+        # plain entry point, out of place
+        ref = src.clone()
+        dp = N.DeviceProgram.upload(prog, DEV)
+        hit = torch.zeros(k, 3, n, device=DEV); w = torch.zeros(k, n, device=DEV); mask = torch.zeros(k, n, dtype=torch.uint8, device=DEV)
+        fn = N.lib().rtt_step_nearest_f32 if kind else N.lib().rtt_trace_seq_f32
+        args = [N.ptr(src._pos), N.ptr(src._dir), N.ptr(src.intensity), n, N.ptr(ref._pos), N.ptr(ref._dir), N.ptr(ref.intensity), n, n,
+                N.ptr(dp.dev), dp.host_ptr, dp.n] + ([None] if kind else []) + [N.ptr(hit), N.ptr(w), N.ptr(mask), n, N.stream_handle(DEV)]
+        N.check(fn(*args), "plain")
+        # the product path: in place through a prepared launch, twice on the same planes
+        work = src.clone()
+        rec = K.step_nearest_record(work, prog) if kind else K.trace_sequential_record(work, prog)
+        handles = P.facts_of(prog)[("launches", kind)]
+        assert len(handles) == 1
+        h, ww, m_ = rec.views()
+        assert torch.equal(work._pos, ref._pos) and torch.equal(work._dir, ref._dir) and torch.equal(work.intensity, ref.intensity)
+        assert torch.equal(m_, mask) and torch.equal(ww[mask.bool()], w[mask.bool()]) and torch.equal(h.transpose(1, 2)[mask.bool()], hit.transpose(1, 2)[mask.bool()])
+        first = work.clone()
+        (K.step_nearest_record if kind else K.trace_sequential_record)(work, prog)
+        assert len(handles) == 1                              # found again
+        # a plane tensor that got other storage is another launch: the old handle's addresses must not be used
+        keep = work._pos
+        work._pos.data = first._pos.clone(); work._dir.data = first._dir.clone(); work.intensity.data = first.intensity.clone()
+        (K.step_nearest_record if kind else K.trace_sequential_record)(work, prog)
+        assert keep is work._pos and len(handles) == 1 and handles[0][4][0] == work._pos.data_ptr()
+        again = first.clone()
+        (K.step_nearest_record if kind else K.trace_sequential_record)(again, prog)
+        assert torch.equal(work._pos, again._pos) and len(handles) == 2
+        # a tuning call makes every handle stale; the next call prepares again and gives the same rays
+        assert N.lib().rtt_tune(3, 1) == 0
+        fresh = first.clone()
+        (K.step_nearest_record if kind else K.trace_sequential_record)(fresh, prog)
+        assert torch.equal(fresh._pos, again._pos)
