@@ -145,6 +145,8 @@ class Renderer:
         dev = rays.device
         n = len(rays)
         prog = self.scene._program()
+        if len(prog) > 64:   # (the kernel takes the surfaces to leave out as a 64-bit mask)
+            raise NotImplementedError(f"the renderer shades scenes of at most 64 surfaces (this one has {len(prog)})")
         base = np.ones((max(len(prog), 1), 3), dtype=np.float32)
         skip = 0
         for s, rec in enumerate(prog):

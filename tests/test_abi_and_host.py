@@ -483,3 +483,23 @@ def test_sensor_keeps_pending_hit_lists_in_order(ns):
     assert len(s._pending) == 1 and len(s._locs) == 4 and s._pending_bytes == int(0.4 * 2 ** 30)
     s._record_pending(entries_of, nbytes=2 ** 31)     # one entry larger than the limit is still taken (after settling the rest)
     assert len(s._pending) == 1 and len(s._locs) == 6
+
+
+def test_long_programs_are_cut_into_stretches_for_the_backward(ns, monkeypatch):
+    """Which programs a differentiable trace sweeps in one piece, and where it cuts the others (whole elements, at most
+    12 surfaces per stretch in reverse mode, 64 in forward mode; sensor slots numbered per stretch)."""
+    import raytracetorch_amd.autograd as AG
+    monkeypatch.delenv("RTT_BACKWARD", raising=False)
+    short = scenes.triplet_train(ns, 3, grads=True)
+    assert AG._stretches(short, P.compile_elements(short)) is None                       # 21 surfaces: the sweep's LDS holds them
+    mid = scenes.triplet_train(ns, 4, grads=True, sensors=(1, 3))
+    cut = AG._stretches(mid, P.compile_elements(mid))
+    assert [(len(e), p.shape[0], P.n_sensor_slots(p)) for e, p in cut] == [(1, 7, 0), (2, 8, 1), (1, 7, 0), (2, 8, 1)]
+    assert [e for es, _ in cut for e in es] == mid and all(int(p["sensor_slot"].max()) <= 0 for _, p in cut)
+    long = scenes.triplet_train(ns, 10, grads=True, sensors=(2, 9))
+    prog = P.compile_elements(long)
+    assert sum(p.shape[0] for _, p in AG._stretches(long, prog)) == 72
+    assert not AG.one_sweep(prog, len(long)) and AG.one_sweep(prog[:21], 3) and AG.one_sweep(prog[:28], 1)   # (a single element cannot be cut)
+    monkeypatch.setenv("RTT_BACKWARD", "tangent")
+    assert AG._stretches(mid, P.compile_elements(mid)) is None                           # forward mode has no LDS budget
+    assert [p.shape[0] for _, p in AG._stretches(long, prog)] == [64, 8]
