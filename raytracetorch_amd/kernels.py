@@ -20,7 +20,11 @@ def _check_rays(rays: Rays):
     p, d, w = rays._pos, rays._dir, rays.intensity
     for c in _checked:
         # the very tensors of an earlier call (a stepping loop, an optimisation loop, an in/out pair): already checked
-        if c[0] is not None and c[0]() is p and c[1]() is d and c[2]() is w and p.shape[1] == c[3]:
+        # (a tensor object keeps its identity when it is given other data, `t.data = ...`: what would let a launch read
+        # host memory or another type is looked at again, it costs a few attribute reads)
+        if (c[0] is not None and c[0]() is p and c[1]() is d and c[2]() is w and p.shape[1] == c[3]
+                and p.is_cuda and d.is_cuda and w.is_cuda and p.dtype is torch.float32 and d.dtype is torch.float32
+                and w.dtype is torch.float32 and w.shape[0] == c[3] and d.shape[1] == c[3]):
             return c[3]
     n = _check_rays_full(rays, p, d, w)
     _checked[1] = _checked[0]
