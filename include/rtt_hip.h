@@ -480,7 +480,10 @@ int64_t rtt_sensor_record_bytes(int n_slots, int64_t sens_ld);
  * key 10: rtt_simulate_nearest_staged_f32: 0 (default) every stage writes the rays that come to rest to the output
  * planes itself (seven scattered 4-byte stores for a ray that rests after the first stage), 1 such rays leave one
  * 32-byte record each and a last pass writes them to the planes in index order (measured on the 32-surface scene,
- * 4 Mi rays x 100 bounces: 8 % fewer HBM bytes, 1.5 % more time: the last pass).  Same results.
+ * 4 Mi rays x 100 bounces: 8 % fewer HBM bytes, 1.5 % more time: the last pass).  Same results;
+ * key 11: rtt_trace_seq_adjoint_f32 on a program of spherical lens faces, lens edges and bounded planes only: 1 (default)
+ * runs the instantiation of the kernel that holds just these visits (fewer registers, nothing spilled: 3 % off a
+ * spot-size step at 32 Mi rays), 0 the general one.
  * No counterpart in the reference. */
 int rtt_tune(int key, int value);
 

@@ -525,7 +525,21 @@ struct AdjState {
 // TAPE (with COMPACT): there is no forward sweep; the states come from the tape the forward trace wrote (direction and
 //   path length per surface that the ray's group hit), staged into the same LDS layout, and the positions are walked
 //   from the input positions as above.  io.dir_in and io.inten_in are not read.
-template <class T, int BS, bool COMPACT = false, bool TAPE = false>
+// SET = 1: the program holds nothing but spherical lens faces, lens edges and bounded planes (a lens system in front of a
+// sensor or a stop); the visits of the other configurations are left out of this instantiation.
+#define RTT_DISPATCH_SET(op, CALL)                  \
+  if constexpr (SET == 1) {                         \
+    switch (op) {                                   \
+      case OP_FACE_SNELL: CALL(CFaceSnell); break;  \
+      case OP_EDGE_BLOCK: CALL(CEdgeBlock); break;  \
+      case OP_EDGE_SNELL: CALL(CEdgeSnell); break;  \
+      default: CALL(CDiskPlane); break;             \
+    }                                               \
+  } else {                                          \
+    RTT_DISPATCH(op, CALL)                          \
+  }
+
+template <class T, int BS, bool COMPACT = false, bool TAPE = false, int SET = 0>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT ? 3 : 2, 4))) k_trace_seq_adjoint(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                               Ops ops, AccMap am, AdjointIO a, int vec) {
   static_assert(!TAPE || (COMPACT && LaneOf<T>::N == 2 && BS % 64 == 0), "a tape is swept with compact states, two rays per lane");
@@ -617,7 +631,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
       }                                                                                                \
     }                                                                                                  \
   }
-      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+      RTT_DISPATCH_SET(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
       set_bits(bits, s, hit);
     };
@@ -730,7 +744,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(COMPACT
       };
       RTT_MARK(tm, 3);  // record flags, dispatch
 #define RTT_CALL(CFG) visit_adjoint<CFG>(S, p, d, t, hit, pb, db, ridx, sk, ext)
-      RTT_DISPATCH(op_of(ops, s), RTT_CALL)
+      RTT_DISPATCH_SET(op_of(ops, s), RTT_CALL)
 #undef RTT_CALL
     };
     for (int s = n_surf - 1; s >= 0; --s) reverse_visit(s);

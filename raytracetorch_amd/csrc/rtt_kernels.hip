@@ -3145,6 +3145,7 @@ int64_t adjoint_lds_bytes(int n_surf, int n_acc, int rays_per_lane, bool compact
 constexpr int kMaxDevices = 64;
 int g_adjoint_state = 0;                     // 0: compact states where they buy a third wavefront per SIMD, 1: full states always
 
+int g_adjoint_lens_set = 1;                  // reverse sweep: lens-only programs run the instantiation without the other visits
 int g_late_records = 0;                      // staged bounce loop: rays that rest after the first stage write the planes themselves (0) or leave records (1)
 int g_adjoint_rounds = 3;                    // rounds of resident blocks in the grid of the reverse sweep (capped at 2048 blocks)
 
@@ -3162,26 +3163,26 @@ int compute_units() {
 
 // Dynamic LDS above 64 KB has to be granted per kernel and per device (each device holds its own copy of the code
 // object): done once for the device that is current, remembered per device and instantiation.
-template <class T, int BS, bool COMPACT, bool TAPE>
+template <class T, int BS, bool COMPACT, bool TAPE, int SET = 0>
 int grant_adjoint_lds() {
   static std::atomic<bool> granted[kMaxDevices];
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return RTT_E_LAUNCH;
   if (granted[dev].load(std::memory_order_acquire)) return RTT_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS, COMPACT, TAPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_seq_adjoint<T, BS, COMPACT, TAPE, SET>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           kLdsBytes) != hipSuccess)
     return RTT_E_LAUNCH;
   granted[dev].store(true, std::memory_order_release);
   return RTT_OK;
 }
 
-template <class T, int BS, bool COMPACT = false, bool TAPE = false>
+template <class T, int BS, bool COMPACT = false, bool TAPE = false, int SET = 0>
 int launch_adjoint(const RayIO& io, const RttSurface* prog_dev, int n_surf, const Ops& ops, const AccMap& am, const AdjointIO& a,
                    int vec, int64_t lds, int blocks, hipStream_t st) {
-  const int rc = grant_adjoint_lds<T, BS, COMPACT, TAPE>();
+  const int rc = grant_adjoint_lds<T, BS, COMPACT, TAPE, SET>();
   if (blocks == 0) return RTT_OK;  // a call without rays only prepares the current device, if there is one
   if (rc != RTT_OK) return rc;
-  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS, COMPACT, TAPE>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am,
+  hipLaunchKernelGGL((k_trace_seq_adjoint<T, BS, COMPACT, TAPE, SET>), dim3(blocks), dim3(BS), (size_t)lds, st, io, prog_dev, n_surf, ops, am,
                      a, vec);
   return launch_status();
 }
@@ -3267,11 +3268,23 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
                   aligned8(adj_dir) && aligned8(adj_sens) && aligned8(spot_w);
   if (tape)
     rc = launch_adjoint<f2, kBlock, true, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
-  else if (compact)
-    rc = launch_adjoint<f2, kBlock, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
-  else
-    rc = lanes == 2 ? launch_adjoint<f2, kBlock>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
-                    : launch_adjoint<float, kBlock>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+  else {
+    // a program of lens faces, lens edges and bounded planes only (lenses, stops, a sensor) runs the instantiation that
+    // holds just these visits: a third of the code, fewer registers, nothing spilled
+    bool lens_set = g_adjoint_lens_set != 0;
+    for (int s = 0; s < n_surf && lens_set; ++s) {
+      const int op = (ops.w[s >> 2] >> ((s & 3) * 8)) & 0xff;
+      lens_set = op == OP_FACE_SNELL || op == OP_EDGE_BLOCK || op == OP_EDGE_SNELL || op == OP_DISK_PLANE;
+    }
+    if (compact)
+      rc = lens_set ? launch_adjoint<f2, kBlock, true, false, 1>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                    : launch_adjoint<f2, kBlock, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
+    else if (lanes == 2)
+      rc = lens_set ? launch_adjoint<f2, kBlock, false, false, 1>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+                    : launch_adjoint<f2, kBlock>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
+    else
+      rc = launch_adjoint<float, kBlock>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
+  }
   if (rc != RTT_OK || n_acc == 0) return rc;
   if (n == 0) return hipMemsetAsync(slot_adj, 0, sizeof(double) * n_acc, st) == hipSuccess ? RTT_OK : RTT_E_LAUNCH;
   hipLaunchKernelGGL(k_sum_partials, dim3(n_acc), dim3(kBlock), 0, st, partials, (int)blocks, (int64_t)n_acc, (int64_t)1, slot_adj);
@@ -3975,6 +3988,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 10 && (value == 0 || value == 1)) {
     g_late_records = value;
+    return RTT_OK;
+  }
+  if (key == 11 && (value == 0 || value == 1)) {
+    g_adjoint_lens_set = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;

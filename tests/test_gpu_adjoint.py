@@ -352,8 +352,8 @@ def test_state_placements_agree(ns, state):
     for s, j in pairs:
         masks[s] |= np.uint32(1 << j)
 
-    def run(which):
-        assert lib.rtt_tune(7, which) == 0
+    def run(which, lens_set=1):
+        assert lib.rtt_tune(7, which) == 0 and lib.rtt_tune(11, lens_set) == 0
         try:
             slot_adj = torch.empty(len(pairs), dtype=torch.float64, device=DEV)
             ray_adj = torch.empty((6, n), device=DEV)
@@ -367,7 +367,13 @@ def test_state_placements_agree(ns, state):
             return slot_adj.cpu(), ray_adj.cpu()
         finally:
             lib.rtt_tune(7, 0)
+            lib.rtt_tune(11, 1)
     want, got = run(1), run(state)
     worst = float((got[1] - want[1]).abs().max()) / float(want[1].abs().max())
     assert worst <= 1e-5, worst
     assert float((got[0] - want[0]).abs().max()) <= 1e-5 * float(want[0].abs().max())
+    # the instantiations that hold only the visits of a lens system (this program is one) against the general ones
+    for which in (0, 1):
+        lean, general = run(which, 1), run(which, 0)
+        assert float((lean[1] - general[1]).abs().max()) <= 1e-5 * float(general[1].abs().max())
+        assert float((lean[0] - general[0]).abs().max()) <= 1e-5 * float(general[0].abs().max())
