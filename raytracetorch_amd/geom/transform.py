@@ -14,14 +14,51 @@ Vector3 = Optional[Union[torch.Tensor, List[float], Tuple[float, ...]]]
 Bool3 = Optional[Union[torch.Tensor, List[bool], Tuple[bool, ...]]]
 
 
-def _skew_exp(rot_vec: torch.Tensor) -> torch.Tensor:
-    """geom/transform.py:52-57."""
+def _skew(rot_vec: torch.Tensor) -> torch.Tensor:
     x, y, z = rot_vec
     K = torch.zeros((3, 3), device=rot_vec.device, dtype=rot_vec.dtype)
     K[0, 1], K[0, 2] = -z, y
     K[1, 0], K[1, 2] = z, -x
     K[2, 0], K[2, 1] = -y, x
-    return torch.linalg.matrix_exp(K)
+    return K
+
+
+class _SkewExp(torch.autograd.Function):
+    """R = exp(skew(v)) (geom/transform.py:52-57) with its derivative held ready.  The reference differentiates through
+    `torch.linalg.matrix_exp`, whose backward takes the exponential of a 6x6 block matrix per upstream gradient; the
+    slot Jacobians of a scene ask for hundreds of them at once (one per record slot, batched), which made a pose the
+    most expensive thing to train.  Here the three directional derivatives dR/dv_k are computed once in the forward, as
+    the upper right blocks of exp([[K, G_k], [0, K]]) (the Frechet derivative of the exponential along the generator
+    G_k), and the backward is a contraction with them.  Same R bit for bit, same derivative."""
+    generate_vmap_rule = True
+
+    @staticmethod
+    def forward(rot_vec):
+        K = _skew(rot_vec)
+        blocks = torch.zeros((3, 6, 6), device=rot_vec.device, dtype=rot_vec.dtype)
+        blocks[:, :3, :3] = K
+        blocks[:, 3:, 3:] = K
+        blocks[0, 1, 5], blocks[0, 2, 4] = -1.0, 1.0     # G_x = d skew / d x
+        blocks[1, 0, 5], blocks[1, 2, 3] = 1.0, -1.0     # G_y
+        blocks[2, 0, 4], blocks[2, 1, 3] = -1.0, 1.0     # G_z
+        return torch.linalg.matrix_exp(K), torch.linalg.matrix_exp(blocks)[:, :3, 3:].contiguous()
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(output[1])
+        ctx.mark_non_differentiable(output[1])
+
+    @staticmethod
+    def backward(ctx, grad_R, _):
+        (dR,) = ctx.saved_tensors
+        return (grad_R.unsqueeze(0) * dR).sum(dim=(-2, -1))   # (plain ops: also under the batched backward of a Jacobian)
+
+
+def _skew_exp(rot_vec: torch.Tensor) -> torch.Tensor:
+    """geom/transform.py:52-57."""
+    if rot_vec.requires_grad and torch.is_grad_enabled():
+        return _SkewExp.apply(rot_vec)[0]
+    return torch.linalg.matrix_exp(_skew(rot_vec))
 
 
 class RayTransform(nn.Module):

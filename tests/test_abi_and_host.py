@@ -503,3 +503,24 @@ def test_long_programs_are_cut_into_stretches_for_the_backward(ns, monkeypatch):
     monkeypatch.setenv("RTT_BACKWARD", "tangent")
     assert AG._stretches(mid, P.compile_elements(mid)) is None                           # forward mode has no LDS budget
     assert [p.shape[0] for _, p in AG._stretches(long, prog)] == [64, 8]
+
+
+def test_rotation_matrix_keeps_its_derivative_ready():
+    """exp(skew(v)) of a trainable rotation: the value of torch.linalg.matrix_exp bit for bit, its derivative from the
+    three directional derivatives made in the forward (plain, batched as the slot Jacobians ask for it, float64 check)."""
+    from raytracetorch_amd.geom.transform import _skew, _skew_exp
+    for vec in ([0.3, -0.2, 0.5], [0.0, 0.0, 0.0], [1e-4, 2.0, -1.0]):
+        v = torch.tensor(vec, requires_grad=True)
+        R, ref = _skew_exp(v), torch.linalg.matrix_exp(_skew(v))
+        assert torch.equal(R, ref) and R.grad_fn is not None
+        w = torch.randn(3, 3, generator=torch.Generator().manual_seed(1))
+        (g,), (g_ref,) = torch.autograd.grad((R * w).sum(), v), torch.autograd.grad((ref * w).sum(), v)
+        assert float((g - g_ref).abs().max()) <= 2e-6 * max(1.0, float(g_ref.abs().max()))
+        eye = torch.eye(9)
+        (j,) = torch.autograd.grad(_skew_exp(v).reshape(-1), v, grad_outputs=eye, is_grads_batched=True)
+        (j_ref,) = torch.autograd.grad(torch.linalg.matrix_exp(_skew(v)).reshape(-1), v, grad_outputs=eye, is_grads_batched=True)
+        assert float((j - j_ref).abs().max()) <= 2e-6
+    v64 = torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(_skew_exp, (v64,))
+    with torch.no_grad():
+        assert _skew_exp(v).grad_fn is None      # nothing extra is computed when no gradient can be asked for
