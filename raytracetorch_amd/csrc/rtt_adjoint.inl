@@ -526,7 +526,8 @@ struct AdjState {
 //   path length per surface that the ray's group hit), staged into the same LDS layout, and the positions are walked
 //   from the input positions as above.  io.dir_in and io.inten_in are not read.
 // SET = 1: the program holds nothing but spherical lens faces, lens edges and bounded planes (a lens system in front of a
-// sensor or a stop); the visits of the other configurations are left out of this instantiation.
+// sensor or a stop); the visits of the other configurations are left out of this instantiation.  SET = 2: every record
+// matches a specialised visit; the generic interpreter's visit is left out.
 #define RTT_DISPATCH_SET(op, CALL)                  \
   if constexpr (SET == 1) {                         \
     switch (op) {                                   \
@@ -535,6 +536,9 @@ struct AdjState {
       case OP_EDGE_SNELL: CALL(CEdgeSnell); break;  \
       default: CALL(CDiskPlane); break;             \
     }                                               \
+  } else if constexpr (SET == 2) {                  \
+    constexpr int NG = 1;                           \
+    RTT_DISPATCH_NG(op, CALL)                       \
   } else {                                          \
     RTT_DISPATCH(op, CALL)                          \
   }

@@ -306,6 +306,22 @@ __device__ __forceinline__ int op_of(const Ops& ops, int s) { return (ops.w[s >>
     default: CALL(CGeneric); break;                    \
   }
 
+// NG = 1: the program holds no record that needs the generic interpreter (the host has looked); its visit is left out.
+#define RTT_DISPATCH_NG(op, CALL)                         \
+  if constexpr (NG == 1) {                                \
+    switch (op) {                                         \
+      case OP_FACE_SNELL: CALL(CFaceSnell); break;        \
+      case OP_EDGE_BLOCK: CALL(CEdgeBlock); break;        \
+      case OP_EDGE_SNELL: CALL(CEdgeSnell); break;        \
+      case OP_DISK_PLANE: CALL(CDiskPlane); break;        \
+      case OP_MIRROR_CAP: CALL(CMirrorCap); break;        \
+      case OP_CYL_FACE_SNELL: CALL(CCylFaceSnell); break; \
+      default: CALL(CCylSide); break;                     \
+    }                                                     \
+  } else {                                                \
+    RTT_DISPATCH(op, CALL)                                \
+  }
+
 // Record views.  The arithmetic reads record fields through a view so that the same templates serve the
 // plain trace (fields are wave-uniform floats in scalar registers) and the tangent trace (fields are
 // dual numbers carrying d(field)/d(parameter)).
@@ -1680,7 +1696,7 @@ DI void offer(T t, int s, T& tmin, typename WinOf<T>::type& win) {
   win = isel(take, s, win);
 }
 
-template <class T>
+template <class T, int NG = 0>
 DI T test_one(const RttSurface* __restrict__ prog, int op, int s, V3<T> p, V3<T> d) {
   const RecF S{prog[s]};
   Frames<T> f;
@@ -1690,7 +1706,7 @@ DI T test_one(const RttSurface* __restrict__ prog, int op, int s, V3<T> p, V3<T>
     const auto valid = test_surface<CFG>(S, p, d, f, t_raw);   \
     t = masked_t<CFG>(S, t_raw, valid);                        \
   }
-  RTT_DISPATCH(op, RTT_CALL)
+  RTT_DISPATCH_NG(op, RTT_CALL)
 #undef RTT_CALL
   return t;
 }
@@ -1751,7 +1767,7 @@ DI float first_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane
 DI float push_f(int to, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(to << 2, __float_as_int(v))); }
 
 // `use_act`: rays whose `act` is false take no part in the search and do not hold an element back.
-template <class T>
+template <class T, int NG = 0>
 DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const CullLanes& L, V3<T> p, V3<T> d, T& tmin,
                 typename WinOf<T>::type& win, uint64_t skip, typename LaneOf<T>::M act, bool use_act) {
   tmin = splat<T>(kInf);
@@ -1759,7 +1775,7 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const CullLanes
   if (L.n == 0) {
     for (int s = 0; s < n_surf; ++s) {
       if ((skip >> s) & 1) continue;  // surfaces left out of the competition (wave-uniform)
-      offer(test_one<T>(prog, lane_i(L.op, s), s, p, d), s, tmin, win);
+      offer(test_one<T, NG>(prog, lane_i(L.op, s), s, p, d), s, tmin, win);
     }
   } else {
     // Front-to-back over the elements, in the order the wavefront's first ray meets their bounding spheres
@@ -1812,7 +1828,7 @@ DI void nearest(const RttSurface* __restrict__ prog, int n_surf, const CullLanes
       const int s0 = fc & 0xff, s1 = s0 + (fc >> 8);
       for (int s = s0; s < s1; ++s) {
         if ((skip >> s) & 1) continue;
-        offer(test_one<T>(prog, lane_i(L.op, s), s, p, d), s, tmin, win);
+        offer(test_one<T, NG>(prog, lane_i(L.op, s), s, p, d), s, tmin, win);
       }
     }
   }
@@ -1865,7 +1881,7 @@ __global__ void __launch_bounds__(kBlock) k_ray_cast(const float* __restrict__ p
 // ballots, so its trip count is wave-uniform; the surface index goes through an opaque copy, otherwise the
 // compiler uses the equality `win == s` to address the record per lane (vector loads, one register set per field)
 // and drops the loop.
-template <class T>
+template <class T, int NG = 0>
 DI void serve_winners(const RttSurface* __restrict__ prog, int opv, typename WinOf<T>::type win, T t,
                       typename LaneOf<T>::M pend, Ray<T>& r, const SensorIO& se, int64_t i, int nv) {
   constexpr int N = LaneOf<T>::N;
@@ -1895,7 +1911,7 @@ DI void serve_winners(const RttSurface* __restrict__ prog, int opv, typename Win
     Frames<T> f = to_frames<CFG>(S, r.p, r.d);         \
     interact<CFG>(S, f, t, mine, r, se, i, nv);        \
   }
-      RTT_DISPATCH(lane_i(opv, su), RTT_CALL)
+      RTT_DISPATCH_NG(lane_i(opv, su), RTT_CALL)
 #undef RTT_CALL
     }
   }
@@ -1938,7 +1954,7 @@ struct StageIO {
 #ifndef RTT_STAGE_WAVES
 #define RTT_STAGE_WAVES 4
 #endif
-template <class T, bool SINGLE, bool STAGE = false>
+template <class T, bool SINGLE, bool STAGE = false, int NG = 0>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STAGE ? RTT_STAGE_WAVES : 4, 4))) k_simulate_nearest(RayIO io, const RttSurface* __restrict__ prog_, int n_surf,
                                                              Ops ops, Cull cull, int max_bounces_,
                                                              int32_t* __restrict__ winner,
@@ -2019,7 +2035,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STA
       typename WinOf<T>::type win;
       // when the cast result is wanted for every ray (also those without intensity), no ray is left out of
       // the culling decisions
-      nearest<T>(prog, n_surf, cl, r.p, r.d, tmin, win, 0, act, !(winner && b == 0));
+      nearest<T, NG>(prog, n_surf, cl, r.p, r.d, tmin, win, 0, act, !(winner && b == 0));
       seb.bounce = (STAGE ? st.bounce0 : 0) + b;
       if (winner && b == 0 && live) {  // Scene.ray_cast result of the first bounce, for every ray
 #pragma unroll
@@ -2042,7 +2058,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(STA
           taken[k] += (a && won) ? 1 : 0;
         }
       }
-      serve_winners<T>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
+      serve_winners<T, NG>(prog, cl.op, win, tmin, pend, r, seb, i, nv);
     }
     if (STAGE) {
       // Places in the next stage's planes: one atomic per block (thousands of wavefronts adding to one address take
@@ -2716,6 +2732,18 @@ Ops make_ops(const RttSurface* host, int n_surf) {
   return ops;
 }
 
+int g_lean_bounce_loop = 1;   // bounce loops of programs without a generic record run the instantiation without that visit
+
+// Whether no record of the program needs the generic interpreter (every one matches a specialised visit): the bounce
+// loops then run an instantiation that leaves it out, which takes the kernels below the register cap of four
+// wavefronts per SIMD with less (or nothing) spilled.
+bool no_generic_visit(const Ops& ops, const RttSurface* host, int n_surf) {
+  if (!host || !g_lean_bounce_loop) return false;
+  for (int s = 0; s < n_surf; ++s)
+    if (((ops.w[s >> 2] >> ((s & 3) * 8)) & 0xff) == OP_GENERIC) return false;
+  return true;
+}
+
 // ---- bounding spheres for the culling nearest-hit search -----------------------------------------------
 // sagitta of a conic at height r, limited to the reach of the half-surface bound |z c| < 1
 float conic_sag(float c, float c1k, float r) {
@@ -3276,11 +3304,14 @@ int trace_seq_adjoint(const float* pos_in, const float* dir_in, const float* int
       const int op = (ops.w[s >> 2] >> ((s & 3) * 8)) & 0xff;
       lens_set = op == OP_FACE_SNELL || op == OP_EDGE_BLOCK || op == OP_EDGE_SNELL || op == OP_DISK_PLANE;
     }
+    const bool lean = g_adjoint_lens_set != 0 && no_generic_visit(ops, prog_host, n_surf);   // (no record for the interpreter)
     if (compact)
       rc = lens_set ? launch_adjoint<f2, kBlock, true, false, 1>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+           : lean   ? launch_adjoint<f2, kBlock, true, false, 2>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
                     : launch_adjoint<f2, kBlock, true>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
     else if (lanes == 2)
       rc = lens_set ? launch_adjoint<f2, kBlock, false, false, 1>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
+           : lean   ? launch_adjoint<f2, kBlock, false, false, 2>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st)
                     : launch_adjoint<f2, kBlock>(io, prog_dev, n_surf, ops, am, a, vec, lds, (int)blocks, st);
     else
       rc = launch_adjoint<float, kBlock>(io, prog_dev, n_surf, ops, am, a, 0, lds, (int)blocks, st);
@@ -3479,8 +3510,13 @@ int rtt_step_nearest_f32(const float* pos_in, const float* dir_in, const float* 
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out) &&
                   (sens_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(sens_mask) & 1u) == 0;
-  hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
-                     n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), 1, winner, (int32_t*)nullptr, se, vec);
+  const Ops ops = make_ops(prog_host, n_surf);
+  if (no_generic_visit(ops, prog_host, n_surf))
+    hipLaunchKernelGGL((k_simulate_nearest<f2, true, false, 1>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io,
+                       prog_dev, n_surf, ops, make_cull(prog_host, n_surf), 1, winner, (int32_t*)nullptr, se, vec);
+  else
+    hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+                       n_surf, ops, make_cull(prog_host, n_surf), 1, winner, (int32_t*)nullptr, se, vec);
   return launch_status();
 }
 
@@ -3614,9 +3650,13 @@ int rtt_simulate_nearest_f32(const float* pos_in, const float* dir_in, const flo
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const int vec = (ld_in % 2 == 0) && (ld_out % 2 == 0) && aligned8(pos_in) && aligned8(dir_in) &&
                   aligned8(inten_in) && aligned8(pos_out) && aligned8(dir_out) && aligned8(inten_out);
-  hipLaunchKernelGGL((k_simulate_nearest<f2, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
-                     n_surf, make_ops(prog_host, n_surf), make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces,
-                     se, vec);
+  const Ops ops = make_ops(prog_host, n_surf);
+  if (no_generic_visit(ops, prog_host, n_surf))
+    hipLaunchKernelGGL((k_simulate_nearest<f2, false, false, 1>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io,
+                       prog_dev, n_surf, ops, make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces, se, vec);
+  else
+    hipLaunchKernelGGL((k_simulate_nearest<f2, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, (hipStream_t)stream, io, prog_dev,
+                       n_surf, ops, make_cull(prog_host, n_surf), max_bounces, (int32_t*)nullptr, bounces, se, vec);
   return launch_status();
 }
 
@@ -3677,6 +3717,7 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
   auto aligned8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; };
   const Ops ops = make_ops(prog_host, n_surf);
   const Cull cull = make_cull(prog_host, n_surf);
+  const bool lean = no_generic_visit(ops, prog_host, n_surf);
   int done = 0;
   for (int s = 0; s < kMaxStages && done < max_bounces; ++s) {
     const int todo = kStageBounces[s] < max_bounces - done ? kStageBounces[s] : max_bounces - done;
@@ -3712,8 +3753,12 @@ int rtt_simulate_nearest_staged_f32(const float* pos_in, const float* dir_in, co
     // the number of rays of a later stage is known on the device only: a bounded grid walks over it
     int grid = grid_for(n, 2);
     if (s > 0 && grid > 8192) grid = 8192;
-    hipLaunchKernelGGL((k_simulate_nearest<f2, false, true>), dim3(grid), dim3(kBlock), 0, sm, io, prog_dev, n_surf, ops, cull, todo,
-                       (int32_t*)nullptr, bounces, se, vec, st);
+    if (lean)
+      hipLaunchKernelGGL((k_simulate_nearest<f2, false, true, 1>), dim3(grid), dim3(kBlock), 0, sm, io, prog_dev, n_surf, ops, cull,
+                         todo, (int32_t*)nullptr, bounces, se, vec, st);
+    else
+      hipLaunchKernelGGL((k_simulate_nearest<f2, false, true>), dim3(grid), dim3(kBlock), 0, sm, io, prog_dev, n_surf, ops, cull, todo,
+                         (int32_t*)nullptr, bounces, se, vec, st);
     if (launch_status() != RTT_OK) return RTT_E_LAUNCH;
     done += todo;
     if (last && s > 0 && g_late_records) {
@@ -3835,6 +3880,7 @@ struct RttLaunch {
   RayIO io;
   const RttSurface* prog_dev;
   int n_surf, vec, n_slots, variant;
+  int lean;  // one bounce: no record of the program needs the generic visit
   int64_t sens_ld;
   Ops ops;
   Cull cull;
@@ -3885,6 +3931,7 @@ int rtt_prepare_step_nearest_f32(const float* pos_in, const float* dir_in, const
   if (rc != RTT_OK) return rc;
   RttLaunch* h = *out;
   h->kind = 1;
+  h->lean = no_generic_visit(h->ops, prog_host, n_surf) ? 1 : 0;
   h->cull = make_cull(prog_host, n_surf);
   h->variant = 2;
   h->grid = (unsigned)grid_for(n, 2);
@@ -3910,8 +3957,12 @@ int rtt_launch_prepared(const RttLaunch* h, void* sens_base, void* stream) {
     se.zero_slots = h->n_slots;   // the kernel clears the mask entries of its rays before the bounce
     // (8-byte accesses also need the masks' pairs 2-byte aligned: an odd sens_ld or base falls back to 4-byte accesses)
     const int vec = h->vec && (h->sens_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(se.mask) & 1u) == 0;
-    hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops, h->cull,
-                       1, (int32_t*)nullptr, (int32_t*)nullptr, se, vec);
+    if (h->lean)
+      hipLaunchKernelGGL((k_simulate_nearest<f2, true, false, 1>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf,
+                         h->ops, h->cull, 1, (int32_t*)nullptr, (int32_t*)nullptr, se, vec);
+    else
+      hipLaunchKernelGGL((k_simulate_nearest<f2, true>), dim3(h->grid), dim3(kBlock), 0, st, h->io, h->prog_dev, h->n_surf, h->ops,
+                         h->cull, 1, (int32_t*)nullptr, (int32_t*)nullptr, se, vec);
     return launch_status();
   }
   switch (h->variant) {
@@ -3992,6 +4043,10 @@ int rtt_tune(int key, int value) {
   }
   if (key == 11 && (value == 0 || value == 1)) {
     g_adjoint_lens_set = value;
+    return RTT_OK;
+  }
+  if (key == 12 && (value == 0 || value == 1)) {
+    g_lean_bounce_loop = value;
     return RTT_OK;
   }
   return RTT_E_SIZE;

@@ -132,7 +132,7 @@ def test_entry_points_validate_before_touching_the_gpu():
     lib.rtt_release_prepared(h)
     lib.rtt_release_prepared(None)
     assert lib.rtt_sensor_record_bytes(2, 10) == 340 and lib.rtt_sensor_record_bytes(1, 3) == 52 and lib.rtt_sensor_record_bytes(0, 8) == 0
-    assert lib.rtt_tune(10, 2) == E_SIZE and lib.rtt_tune(10, 0) == 0 and lib.rtt_tune(11, 1) == 0 and lib.rtt_tune(12, 0) == E_SIZE
+    assert lib.rtt_tune(10, 2) == E_SIZE and lib.rtt_tune(10, 0) == 0 and lib.rtt_tune(11, 1) == 0 and lib.rtt_tune(12, 1) == 0 and lib.rtt_tune(13, 0) == E_SIZE
     # the staged bounce loop: distinct output planes, an aligned workspace of the stated size, no Fresnel surface
     assert lib.rtt_simulate_nearest_staged_workspace_bytes(7) == 256 + 768 + (8 * 4 + 1) * 8   # counters, two sets of compact planes (to 256 B), records and marks of 8 rays
     big = (ctypes.c_float * 1024)()

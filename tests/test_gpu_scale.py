@@ -487,16 +487,18 @@ def test_staged_bounce_loop_equals_the_single_launch(ns, case, n, monkeypatch):
     src._pos
     from raytracetorch_amd import _native as N
     results = []
-    # (single launch; stages that write the output planes themselves; stages whose late rays leave records for a last pass)
-    for min_rays, late_records in ((1 << 40, 0), (1, 0), (1, 1)):
+    # (single launch; stages that write the output planes themselves; stages whose late rays leave records for a last pass;
+    # single launch and stages through the instantiations that keep the generic visit, which these programs do not need)
+    for min_rays, late_records, lean in ((1 << 40, 0, 1), (1, 0, 1), (1, 1, 1), (1 << 40, 0, 0), (1, 0, 0)):
         monkeypatch.setattr(K, "STAGED_MIN_RAYS", min_rays)
         assert K.staged_bounce_loop(n, bounces, prog) == (min_rays == 1)
         rays = src.clone()
-        assert N.lib().rtt_tune(10, late_records) == 0
+        assert N.lib().rtt_tune(10, late_records) == 0 and N.lib().rtt_tune(12, lean) == 0
         try:
             taken, (hit, keys) = K.simulate_nearest(rays, prog, bounces, want_bounces=True, first_capacity=1000 if case == "cavity" else None)
         finally:
             N.lib().rtt_tune(10, 0)
+            N.lib().rtt_tune(12, 1)
         order = torch.argsort(keys[:, 0].to(torch.int64) * (n + 1) + keys[:, 1].to(torch.int64))
         results.append((rays, taken, hit[order], keys[order]))
     ra, ta, ha, ka = results[0]
