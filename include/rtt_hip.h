@@ -447,7 +447,8 @@ int rtt_spot_groups_f32(const float* x, const float* y, const float* w, const ui
  * launch (NULL for a program without sensor surfaces): hit planes [slots][3][sens_ld] float, then intensities
  * [slots][sens_ld] float, then masks [slots][sens_ld] bytes, as rtt_trace_seq_f32 / rtt_step_nearest_f32 fill their three
  * buffers (the bounce clears the masks first).  The ray planes, the device program and sens_ld are bound by the handle:
- * the caller keeps them alive and prepares again when any of them, or an rtt_tune setting, changes (RTT_E_KIND: stale).
+ * the caller keeps them alive and prepares again when any of them, or an rtt_tune setting, changes (RTT_E_KIND: stale;
+ * also when the launch is made with another device current than the handle was prepared with).
  * A handle may be launched from one thread at a time.  n >= 1; prog_host is required. */
 typedef struct RttLaunch RttLaunch;
 int rtt_prepare_trace_seq_f32(const float* pos_in, const float* dir_in, const float* inten_in, int64_t ld_in,

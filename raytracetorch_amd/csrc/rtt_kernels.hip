@@ -3880,7 +3880,8 @@ struct RttLaunch {
   RayIO io;
   const RttSurface* prog_dev;
   int n_surf, vec, n_slots, variant;
-  int lean;  // one bounce: no record of the program needs the generic visit
+  int lean;    // one bounce: no record of the program needs the generic visit
+  int device;  // the device that was current when the handle was made (its planes live there), -1 = unknown
   int64_t sens_ld;
   Ops ops;
   Cull cull;
@@ -3908,6 +3909,7 @@ int rtt_prepare_trace_seq_f32(const float* pos_in, const float* dir_in, const fl
   if (!h) return RTT_E_LAUNCH;
   h->kind = 0;
   h->epoch = g_tune_epoch;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
   h->io = {pos_in, dir_in, inten_in, ld_in, pos_out, dir_out, inten_out, ld_out, n};
   h->prog_dev = prog_dev;
   h->n_surf = n_surf;
@@ -3941,6 +3943,8 @@ int rtt_prepare_step_nearest_f32(const float* pos_in, const float* dir_in, const
 int rtt_launch_prepared(const RttLaunch* h, void* sens_base, void* stream) {
   if (!h) return RTT_E_NULL;
   if (h->epoch != g_tune_epoch) return RTT_E_KIND;  // prepared under other rtt_tune settings: prepare again
+  int dev = -1;
+  if (h->device >= 0 && (hipGetDevice(&dev) != hipSuccess || dev != h->device)) return RTT_E_KIND;  // another device is current
   if (h->n_slots > 0 && !sens_base) return RTT_E_NULL;
   if (misaligned(sens_base)) return RTT_E_ALIGN;
   // one allocation holds the record: hit planes [slots][3][ld], intensities [slots][ld], masks [slots][ld] bytes
