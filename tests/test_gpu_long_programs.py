@@ -160,6 +160,27 @@ def test_ray_cast_and_step_over_ninety_six_surfaces(ns, copies):
             assert np.array_equal(la, lb) and np.array_equal(wa, wb)
 
 
+def test_a_step_of_a_long_scene_under_paths_adds_one_snapshot(ns):
+    """Scene.step() with the rays wrapped in Paths (rays/ray.py:100-207): the bounce of a 96-surface scene moves the same
+    rays as without the wrapper and leaves one snapshot."""
+    els = sum((scenes.naive32(ns, 100.0 * k) for k in range(3)), [])
+    src = _scattered_rays(ns, 5000, 2)
+    results = []
+    for wrap in (False, True):
+        scene = ns.Scene()
+        for el in els:
+            el.reset() if hasattr(el, "reset") else None
+            scene.add_element(el)
+        scene._build_index_maps()
+        scene.rays = ns.Paths(src.to(DEV)) if wrap else src.to(DEV)
+        scene.step()
+        results.append(scene.rays)
+    plain, wrapped = results
+    assert torch.equal(wrapped.unwrap().pos, plain.pos) and torch.equal(wrapped.unwrap().intensity, plain.intensity)
+    hist = wrapped.get_history()
+    assert len(hist) == 2 and torch.equal(hist[1], plain.pos.cpu()) and not torch.equal(hist[0], hist[1])
+
+
 def _objective(ns, seed):
     def objective(els, rays):
         g = torch.Generator().manual_seed(seed)
