@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profiles: kernel stats + counters of every workload with the current library, traffic files with its hash.
+# Profiles: kernel stats + counters of every workload with the current library, traffic files with its hash.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp

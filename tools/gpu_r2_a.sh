@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 GPU pass A: full GPU test suite, default bench, 2-rank gloo rehearsal, other workloads, counters of system5 / naive32.
+# GPU pass A: full GPU test suite, default bench, 2-rank gloo rehearsal, other workloads, counters of system5 / naive32.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp

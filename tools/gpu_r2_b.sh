@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 GPU pass B: reverse-mode tests, spot step in both modes, kernel trace of the spot step.
+# GPU pass B: reverse-mode tests, spot step in both modes, kernel trace of the spot step.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 evidence pass: GPU tests, bench lines of every workload, 2-rank rehearsal, single-rank RCCL, profiles + traffic files.
+# Evidence pass: GPU tests, bench lines of every workload, 2-rank rehearsal, single-rank RCCL, profiles + traffic files.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp

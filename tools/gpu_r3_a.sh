@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, first GPU call: gradient tests with the register-resident reverse sweep, then the spot step with states in
+# gradient tests with the register-resident reverse sweep, then the spot step with states in
 # registers against states in LDS (three alternations), with a kernel trace of each.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"

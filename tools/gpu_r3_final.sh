@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence pass: bench lines of every workload, 2-rank rehearsal, single-rank RCCL, backward modes, latencies, smoke.
+# Evidence pass: bench lines of every workload, 2-rank rehearsal, single-rank RCCL, backward modes, latencies, smoke.
 # (GPU tests: tools/gpu_tests.sh; counters and traffic files: tools/gpu_profiles_r3.sh, run before this with the same library.)
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
