@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--tune-adjoint-rounds", type=int, default=0, help="rounds of resident blocks in the grid of the reverse-mode backward (experiment)")
     ap.add_argument("--tune-lens-set", type=int, default=-1, help="0: the reverse sweep of a lens-only program runs the instantiation with every visit (experiment)")
     ap.add_argument("--tune-lean-bounces", type=int, default=-1, help="0: the bounce loops always run the instantiation with the generic visit (experiment)")
+    ap.add_argument("--tune-moments-blocks", type=int, default=0, help="override the grid of the spot-moment passes (experiment)")
     ap.add_argument("--tune-late-records", type=int, default=-1, help="0: every stage of the staged bounce loop writes the output planes itself (experiment)")
     ap.add_argument("--tune-adjoint-state", type=int, default=-1, help="1: the reverse-mode backward keeps its states in LDS also for short programs")
     return ap.parse_args()
@@ -495,6 +496,8 @@ def main():
         _native.check(_native.lib().rtt_tune(11, a.tune_lens_set), "rtt_tune")
     if a.tune_lean_bounces >= 0:
         _native.check(_native.lib().rtt_tune(12, a.tune_lean_bounces), "rtt_tune")
+    if a.tune_moments_blocks:
+        _native.check(_native.lib().rtt_tune(4, a.tune_moments_blocks), "rtt_tune")
     if a.tune_late_records >= 0:
         _native.check(_native.lib().rtt_tune(10, a.tune_late_records), "rtt_tune")
     if a.tune_adjoint_rounds:
